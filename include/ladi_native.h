@@ -1,0 +1,190 @@
+/*
+ * libladi_native — C ABI of the MI355X-native LaDI-VTON denoising hot path.
+ *
+ * The reference (miccunifi/ladi-vton) has no FFI / operator registry: its seam is the Python nn.Module duck type that
+ * StableDiffusionTryOnePipeline is constructed from (src/vto_pipelines/tryon_pipe.py:56-68,129-137; built at
+ * src/inference.py:212-220).  Each group of entry points below replaces exactly one of those modules; the citation
+ * next to it is the reference interface it stands in for.  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a negative code on failure; ladi_last_error() returns a message
+ *     (thread local).  Nothing throws across the boundary.
+ *   - Pointers named *_dev are DEVICE pointers owned by the caller (e.g. torch allocations); the library never frees
+ *     them.  `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).  All work is
+ *     enqueued asynchronously on that stream; no entry point synchronises except where stated.
+ *   - dtype codes: 0 = float32, 1 = float16.
+ *   - Handles are not thread-safe (one pipeline per process per GPU, as in the reference).
+ *   - The library has NO CPU fallback: without a gfx950 device every compute entry point fails.
+ */
+#ifndef LADI_NATIVE_H
+#define LADI_NATIVE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LADI_F32 0
+#define LADI_F16 1
+
+const char* ladi_last_error(void);
+int ladi_version(void);
+/* number of visible HIP devices (0 when there is no GPU); never fails */
+int ladi_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Weight store: host-side staging of a diffusers-format state_dict (replaces nn.Module.load_state_dict,
+ * hubconf.py:28,39,55; key names per SURVEY.md App. A.6).  Data is copied; the caller may free its buffer.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct ladi_weights ladi_weights;
+ladi_weights* ladi_weights_create(void);
+int ladi_weights_add(ladi_weights* ws, const char* key, const void* host_data, int dtype, int ndim, const int64_t* shape);
+int ladi_weights_count(const ladi_weights* ws);
+void ladi_weights_destroy(ladi_weights* ws);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * UNet — replaces diffusers UNet2DConditionModel as built by hubconf.py:31-39 (in_channels = 31) and called at
+ * tryon_pipe.py:732: unet(latent_model_input, t, encoder_hidden_states=prompt_embeds).sample
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int in_channels, out_channels;
+    int block_out_channels[4];
+    int num_heads[4];            /* diffusers "attention_head_dim" used as head COUNT; head dim must be 64 */
+    int layers_per_block;
+    int cross_attention_dim;
+    int norm_num_groups;
+    float norm_eps;
+} ladi_unet_config;
+typedef struct ladi_unet ladi_unet;
+ladi_unet* ladi_unet_create(const ladi_unet_config* cfg, const ladi_weights* ws);
+void ladi_unet_destroy(ladi_unet* u);
+/* encoder_hidden_states [n, L, cross_attention_dim] fp16 dense; precomputes the cross-attention K/V of all blocks */
+int ladi_unet_set_context(ladi_unet* u, const void* ehs_dev, int n, int L, void* stream);
+/* sample [n, in_channels, h, w] NCHW (dtype), scalar timestep, out [n, out_channels, h, w] NCHW (out_dtype) */
+int ladi_unet_forward(ladi_unet* u, const void* sample_dev, int dtype, int n, int h, int w, float timestep, void* out_dev,
+                      int out_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * VAE — replaces src/models/AutoencoderKL.py AutoencoderKL.encode (:145-157) / .decode (:174-188) with the EMASC
+ * wiring of src/models/vae.py Encoder.forward (:99-119) / Decoder.forward (:183-212).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int in_channels, out_channels, latent_channels;
+    int block_out_channels[4];
+    int layers_per_block;
+    int norm_num_groups;
+    float scaling_factor;
+} ladi_vae_config;
+typedef struct ladi_vae ladi_vae;
+ladi_vae* ladi_vae_create(const ladi_vae_config* cfg, const ladi_weights* ws);
+void ladi_vae_destroy(ladi_vae* v);
+/* x [B,3,H,W] NCHW (dtype) -> moments [B, 2*latent, H/8, W/8] NCHW fp32 (quant_conv applied) and, when feats_dev is
+ * non-NULL, the five intermediate features idx1..5 written NHWC fp16 into caller buffers
+ * ([B,H,W,c0] [B,H,W,c0] [B,H/2,W/2,c0] [B,H/4,W/4,c1] [B,H/8,W/8,c2], c = block_out_channels). */
+int ladi_vae_encode(ladi_vae* v, const void* x_dev, int dtype, int B, int H, int W, float* moments_dev, void* const* feats_dev,
+                    void* stream);
+/* z [B,latent,h,w] NCHW fp32 (already divided by scaling_factor, as vae.decode receives it), skips_dev = NULL or five
+ * NHWC fp16 EMASC outputs (idx1..5 order) -> sample [B,3,8h,8w] NCHW (out_dtype), NOT post-processed. */
+int ladi_vae_decode(ladi_vae* v, const float* z_dev, int B, int h, int w, const void* const* skips_dev, void* sample_dev,
+                    int out_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * EMASC — replaces src/models/emasc.py EMASC.forward (:37-40); mask_features (src/utils/data_utils.py:4-16) can be
+ * fused by passing the binarised full-resolution mask.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct { int n; int in_channels[8]; int out_channels[8]; } ladi_emasc_config;
+typedef struct ladi_emasc ladi_emasc;
+ladi_emasc* ladi_emasc_create(const ladi_emasc_config* cfg, const ladi_weights* ws);
+void ladi_emasc_destroy(ladi_emasc* e);
+/* feats_dev[i]: NHWC fp16 [B, hs[i], wss[i], in_channels[i]] ; outs_dev[i]: NHWC fp16 [B, hs[i], wss[i], out_channels[i]].
+ * mask_dev: NULL, or [B, Hm, Wm] fp16 binary mask at full resolution (Hm = hs[0]): out *= (1 - nearest(mask)). */
+int ladi_emasc_forward(ladi_emasc* e, const void* const* feats_dev, const int* hs, const int* wss, int B, const void* mask_dev,
+                       int Hm, int Wm, void* const* outs_dev, void* stream);
+/* stand-alone mask_features on one NHWC fp16 feature map (in place): feat *= (1 - nearest(mask -> h x w)) */
+int ladi_mask_features(void* feat_dev, int B, int h, int w, int C, const void* mask_dev, int Hm, int Wm, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Inversion adapter — replaces src/models/inversion_adapter.py InversionAdapter.forward (:22-28), dims hubconf.py:17-24
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct { int hidden, heads, mlp_dim, head_hidden, out_dim; float layer_norm_eps; } ladi_adapter_config;
+typedef struct ladi_adapter ladi_adapter;
+ladi_adapter* ladi_adapter_create(const ladi_adapter_config* cfg, const ladi_weights* ws);
+void ladi_adapter_destroy(ladi_adapter* a);
+/* x [B, T, hidden] fp16 dense -> out [B, out_dim] fp16 */
+int ladi_adapter_forward(ladi_adapter* a, const void* x_dev, int B, int T, void* out_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Scheduler — replaces diffusers DDIMScheduler / PNDMScheduler (skip_prk_steps) set_timesteps + step
+ * (tryon_pipe.py:650-651,740).  kind: 0 = DDIM, 1 = PNDM.
+ * ------------------------------------------------------------------------------------------------------------- */
+/* host helper: writes the N (DDIM) or N+1 (PNDM) timesteps; returns their count, or negative on error */
+int ladi_sched_timesteps(int kind, int num_inference_steps, int* timesteps_out, int cap);
+/* host helper: default alphas_cumprod (scaled_linear 0.00085..0.012, 1000 steps), out[1000] */
+int ladi_sched_alphas_cumprod(float* out);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Whole-loop fast path — StableDiffusionTryOnePipeline.__call__ steps 4-11 (tryon_pipe.py:630-753) in one call.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int batch, height, width;
+    int in_dtype;                      /* dtype of image / mask_image / pose_map / warped_cloth */
+    const void* image_dev;             /* [B,3,H,W] in [-1,1] */
+    const void* mask_image_dev;        /* [B,1,H,W] in [0,1] (binarised at 0.5 like prepare_mask_and_masked_image) */
+    const void* pose_map_dev;          /* [B,P,H,W] */
+    const void* warped_cloth_dev;      /* [B,3,H,W] or NULL (cloth_input_type == 'none') */
+    int pose_channels;
+    const void* prompt_embeds_dev;           /* [B,L,D] fp16 */
+    const void* negative_prompt_embeds_dev;  /* [B,L,D] fp16 (required when guidance_scale > 1) */
+    int L;
+    const float* noise_cloth_dev;      /* fp32 [B,4,h,w]: the three generator draws in pipeline order */
+    const float* noise_latents_dev;
+    const float* noise_masked_dev;
+    int num_inference_steps;
+    float guidance_scale;
+    int scheduler;                     /* 0 DDIM, 1 PNDM */
+    float cloth_cond_rate;
+    int no_pose;
+    int use_graph;                     /* capture the denoising step into a hipGraph and replay it */
+    const float* alphas_cumprod_host;  /* optional [1000] override */
+} ladi_tryon_inputs;
+typedef struct ladi_tryon ladi_tryon;
+/* emasc may be NULL (pipeline without EMASC); handles stay owned by the caller */
+ladi_tryon* ladi_tryon_create(ladi_unet* unet, ladi_vae* vae, ladi_emasc* emasc);
+void ladi_tryon_destroy(ladi_tryon* t);
+/* images_dev: fp32 [B,H,W,3] in [0,1] (decode_latents layout, tryon_pipe.py:356-358); latents_dev: optional fp32 [B,4,h,w] */
+int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images_dev, float* latents_dev, void* stream);
+/* stage times (ms) of the last run: [0] preprocess + VAE encodes + EMASC, [1] denoising loop, [2] decode. Sync first. */
+int ladi_tryon_stage_ms(ladi_tryon* t, float* out3);
+/* run ONLY `iters` UNet forwards (n samples of h x w latents, context already set) bracketed by HIP events on `stream`
+ * and return the average milliseconds per forward (synchronises). Used by bench.py for the roofline figure. */
+int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* avg_ms, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Op-level entry points (kernel parity tests; NHWC fp16 device tensors)
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* src0; const void* src1; int C0, C1, ld0, ld1, Hs, Ws, Ho, Wo, P, ksize, stride, pad, ups;
+    const void* W; int Q, K, ldw; long long bs_src0, bs_w, bs_out, bs_res;
+    const void* bias; int bias_per_pixel; const float* rowadd; const int* rowadd_idx; int rowadd_stride; int act; float out_scale;
+    const void* res0; const void* res1; int ldr0, ldr1; const void* mask; void* out; int ldo; int out_f32;
+    float* stats; int stats_groups;
+} ladi_igemm_desc;
+int ladi_op_igemm(const ladi_igemm_desc* d, int batch, int tile_cfg, void* stream);
+int ladi_op_group_norm(const void* src0, int C0, const void* src1, int C1, int n, int HW, int groups, const void* gamma,
+                       const void* beta, float eps, int silu, const void* add, void* out, float* stats_scratch, void* stream);
+int ladi_op_layer_norm(const void* x, const void* gamma, const void* beta, float eps, int rows, int C, void* out, void* stream);
+int ladi_op_attention(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq,
+                      long long sk, long long sv, long long so, int n, int heads, int Nq, int Nk, float scale, void* stream);
+int ladi_op_softmax_rows(const float* S, int rows, int cols, float scale, void* P, void* stream);
+int ladi_op_small_linear(const void* x, int x_f32, int ldx, const void* W, const void* bias, const void* res, int ldr, int M, int N,
+                         int K, int act, int pre_silu, void* out, int out_f32, int ldo, void* stream);
+int ladi_op_nchw_to_nhwc(const void* src, int dtype, int n, int C, int H, int W, void* dst, int ld, void* stream);
+int ladi_op_nhwc_to_nchw(const void* src, int ld, int n, int C, int H, int W, void* dst, int dtype, void* stream);
+/* one scheduler evaluation on device tensors (fused CFG + DDIM/PLMS update), for scheduler parity tests:
+ * runs evaluations [0, evals) feeding eps_seq[i] ([2B or B][hw][4] fp16 NHWC per evaluation); latents fp32 [B][hw][4] in/out */
+int ladi_op_sched_run(int kind, int steps, const float* alphas_cumprod_host, const void* eps_seq_dev, int evals, int B, int hw,
+                      int cfg, float guidance, float* latents_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,223 @@
+"""Frozen model configurations (the HF hub is unreachable; values per SURVEY.md App. A.0 / hubconf.py:17-55) and the
+deterministic synthetic checkpoint generator.  Shared data: used by the product (bench / smoke build random-init models from it) and by the oracle."""
+import zlib
+from collections import OrderedDict
+
+import torch
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs: "full" = released LaDI-VTON hyper-parameters; "tiny" = same topology, small widths for CPU-sized tests
+# ---------------------------------------------------------------------------------------------------------------
+UNET_FULL = dict(in_channels=31, out_channels=4, block_out_channels=(320, 640, 1280, 1280), num_heads=(5, 10, 20, 20),
+                 layers_per_block=2, cross_attention_dim=1024, norm_num_groups=32, norm_eps=1e-5)
+UNET_TINY = dict(in_channels=31, out_channels=4, block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4),
+                 layers_per_block=2, cross_attention_dim=128, norm_num_groups=32, norm_eps=1e-5)
+VAE_FULL = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
+                layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215)
+VAE_TINY = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(64, 64, 128, 128),
+                layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215)
+EMASC_FULL = dict(in_channels=(128, 128, 128, 256, 512), out_channels=(128, 256, 512, 512, 512))
+EMASC_TINY = dict(in_channels=(64, 64, 64, 64, 128), out_channels=(64, 64, 128, 128, 128))
+ADAPTER_FULL = dict(hidden=1280, heads=16, mlp_dim=5120, head_hidden=5120, out_dim=16384, layer_norm_eps=1e-5)
+ADAPTER_TINY = dict(hidden=128, heads=2, mlp_dim=256, head_hidden=256, out_dim=16 * 128, layer_norm_eps=1e-5)
+
+
+def emasc_for_vae(vae_cfg):
+    """EMASC channel lists implied by a VAE config (hubconf.py:42-44 for the released one)."""
+    b = vae_cfg["block_out_channels"]
+    return dict(in_channels=(b[0], b[0], b[0], b[1], b[2]), out_channels=(b[0], b[1], b[2], b[3], b[3]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# state-dict key/shape enumeration (diffusers 0.14 naming)
+# ---------------------------------------------------------------------------------------------------------------
+def _conv(sd, name, cin, cout, k):
+    sd[name + ".weight"] = (cout, cin, k, k)
+    sd[name + ".bias"] = (cout,)
+
+
+def _lin(sd, name, cin, cout, bias=True):
+    sd[name + ".weight"] = (cout, cin)
+    if bias:
+        sd[name + ".bias"] = (cout,)
+
+
+def _norm(sd, name, c):
+    sd[name + ".weight"] = (c,)
+    sd[name + ".bias"] = (c,)
+
+
+def _resnet(sd, p, cin, cout, temb):
+    _norm(sd, p + ".norm1", cin)
+    _conv(sd, p + ".conv1", cin, cout, 3)
+    if temb:
+        _lin(sd, p + ".time_emb_proj", temb, cout)
+    _norm(sd, p + ".norm2", cout)
+    _conv(sd, p + ".conv2", cout, cout, 3)
+    if cin != cout:
+        _conv(sd, p + ".conv_shortcut", cin, cout, 1)
+
+
+def _transformer(sd, p, c, cross):
+    _norm(sd, p + ".norm", c)
+    _lin(sd, p + ".proj_in", c, c)
+    b = p + ".transformer_blocks.0"
+    for i in (1, 2, 3):
+        _norm(sd, b + ".norm%d" % i, c)
+    for a, kd in (("attn1", c), ("attn2", cross)):
+        _lin(sd, b + "." + a + ".to_q", c, c, bias=False)
+        _lin(sd, b + "." + a + ".to_k", kd, c, bias=False)
+        _lin(sd, b + "." + a + ".to_v", kd, c, bias=False)
+        _lin(sd, b + "." + a + ".to_out.0", c, c)
+    _lin(sd, b + ".ff.net.0.proj", c, 8 * c)
+    _lin(sd, b + ".ff.net.2", 4 * c, c)
+    _lin(sd, p + ".proj_out", c, c)
+
+
+def unet_shapes(cfg):
+    sd = OrderedDict()
+    boc = cfg["block_out_channels"]
+    L = cfg["layers_per_block"]
+    cross = cfg["cross_attention_dim"]
+    temb = boc[0] * 4
+    _conv(sd, "conv_in", cfg["in_channels"], boc[0], 3)
+    _lin(sd, "time_embedding.linear_1", boc[0], temb)
+    _lin(sd, "time_embedding.linear_2", temb, temb)
+    ch = boc[0]
+    for i in range(4):
+        for j in range(L):
+            _resnet(sd, "down_blocks.%d.resnets.%d" % (i, j), ch, boc[i], temb)
+            ch = boc[i]
+            if i < 3:
+                _transformer(sd, "down_blocks.%d.attentions.%d" % (i, j), ch, cross)
+        if i < 3:
+            _conv(sd, "down_blocks.%d.downsamplers.0.conv" % i, ch, ch, 3)
+    _resnet(sd, "mid_block.resnets.0", ch, ch, temb)
+    _transformer(sd, "mid_block.attentions.0", ch, cross)
+    _resnet(sd, "mid_block.resnets.1", ch, ch, temb)
+    rb = list(reversed(boc))
+    for i in range(4):
+        out = rb[i]
+        prev = rb[0] if i == 0 else rb[i - 1]
+        inp = rb[min(i + 1, 3)]
+        for j in range(L + 1):
+            skip = inp if j == L else out
+            rin = prev if j == 0 else out
+            _resnet(sd, "up_blocks.%d.resnets.%d" % (i, j), rin + skip, out, temb)
+            if i > 0:
+                _transformer(sd, "up_blocks.%d.attentions.%d" % (i, j), out, cross)
+        if i < 3:
+            _conv(sd, "up_blocks.%d.upsamplers.0.conv" % i, out, out, 3)
+    _norm(sd, "conv_norm_out", boc[0])
+    _conv(sd, "conv_out", boc[0], cfg["out_channels"], 3)
+    return sd
+
+
+def _vae_attn(sd, p, c):
+    _norm(sd, p + ".group_norm", c)
+    for n in ("query", "key", "value", "proj_attn"):
+        _lin(sd, p + "." + n, c, c)
+
+
+def vae_shapes(cfg):
+    sd = OrderedDict()
+    boc = cfg["block_out_channels"]
+    L = cfg["layers_per_block"]
+    z = cfg["latent_channels"]
+    _conv(sd, "encoder.conv_in", cfg["in_channels"], boc[0], 3)
+    ch = boc[0]
+    for i in range(4):
+        for j in range(L):
+            _resnet(sd, "encoder.down_blocks.%d.resnets.%d" % (i, j), ch, boc[i], None)
+            ch = boc[i]
+        if i < 3:
+            _conv(sd, "encoder.down_blocks.%d.downsamplers.0.conv" % i, ch, ch, 3)
+    _resnet(sd, "encoder.mid_block.resnets.0", ch, ch, None)
+    _vae_attn(sd, "encoder.mid_block.attentions.0", ch)
+    _resnet(sd, "encoder.mid_block.resnets.1", ch, ch, None)
+    _norm(sd, "encoder.conv_norm_out", ch)
+    _conv(sd, "encoder.conv_out", ch, 2 * z, 3)
+    _conv(sd, "quant_conv", 2 * z, 2 * z, 1)
+    _conv(sd, "post_quant_conv", z, z, 1)
+    rb = list(reversed(boc))
+    _conv(sd, "decoder.conv_in", z, rb[0], 3)
+    _resnet(sd, "decoder.mid_block.resnets.0", rb[0], rb[0], None)
+    _vae_attn(sd, "decoder.mid_block.attentions.0", rb[0])
+    _resnet(sd, "decoder.mid_block.resnets.1", rb[0], rb[0], None)
+    ch = rb[0]
+    for i in range(4):
+        for j in range(L + 1):
+            _resnet(sd, "decoder.up_blocks.%d.resnets.%d" % (i, j), ch, rb[i], None)
+            ch = rb[i]
+        if i < 3:
+            _conv(sd, "decoder.up_blocks.%d.upsamplers.0.conv" % i, ch, ch, 3)
+    _norm(sd, "decoder.conv_norm_out", ch)
+    _conv(sd, "decoder.conv_out", ch, cfg["out_channels"], 3)
+    return sd
+
+
+def emasc_shapes(cfg):
+    sd = OrderedDict()
+    for i, (ci, co) in enumerate(zip(cfg["in_channels"], cfg["out_channels"])):
+        _conv(sd, "conv.%d.0" % i, ci, ci, 3)
+        _conv(sd, "conv.%d.2" % i, ci, co, 3)
+    return sd
+
+
+def adapter_shapes(cfg):
+    sd = OrderedDict()
+    h = cfg["hidden"]
+    e = "encoder_layers.0"
+    for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+        _lin(sd, e + ".self_attn." + n, h, h)
+    _norm(sd, e + ".layer_norm1", h)
+    _lin(sd, e + ".mlp.fc1", h, cfg["mlp_dim"])
+    _lin(sd, e + ".mlp.fc2", cfg["mlp_dim"], h)
+    _norm(sd, e + ".layer_norm2", h)
+    _norm(sd, "post_layernorm", h)
+    _lin(sd, "layers.0", h, cfg["head_hidden"])
+    _lin(sd, "layers.3", cfg["head_hidden"], cfg["head_hidden"])
+    _lin(sd, "layers.6", cfg["head_hidden"], cfg["out_dim"])
+    return sd
+
+
+def param_count(shapes):
+    n = 0
+    for s in shapes.values():
+        k = 1
+        for d in s:
+            k *= d
+        n += k
+    return n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# deterministic synthetic checkpoint: order-independent, keyed by name
+# ---------------------------------------------------------------------------------------------------------------
+def _is_norm(key):
+    leaf = key.rsplit(".", 2)[-2]
+    return "norm" in leaf or leaf == "post_layernorm"
+
+
+def synth_tensor(key, shape, scope=""):
+    g = torch.Generator().manual_seed(zlib.crc32((scope + key).encode()) & 0x7FFFFFFF)
+    u = torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1
+    if _is_norm(key):
+        return 1.0 + 0.1 * u if key.endswith(".weight") else 0.1 * u
+    if key.endswith(".weight"):
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        return u * (3.0 / fan_in) ** 0.5     # variance-preserving uniform
+    return u * 0.1                            # biases
+
+
+def synth_state_dict(shapes, scope="", fp16_round=True):
+    """fp32 tensors whose values are exactly representable in fp16 (so weight quantisation is not counted as error)."""
+    sd = OrderedDict()
+    for k, s in shapes.items():
+        t = synth_tensor(k, s, scope)
+        if fp16_round:
+            t = t.half().float()
+        sd[k] = t
+    return sd

@@ -1,0 +1,440 @@
+// extern "C" boundary of libladi_native (see include/ladi_native.h for the contract and reference citations).
+#include "../../include/ladi_native.h"
+#include "runtime.h"
+#include <stdexcept>
+#include <cstring>
+#include <cmath>
+
+using namespace ladi;
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct ladi_weights { WeightStore ws; };
+struct ladi_unet { UNet u; };
+struct ladi_vae { VAE v; };
+struct ladi_emasc { EMASC e; };
+struct ladi_adapter { Adapter a; };
+struct ladi_tryon { TryOn t; };
+
+static_assert(sizeof(ladi_igemm_desc) == sizeof(IGemmArgs), "public igemm descriptor must mirror IGemmArgs");
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename F>
+static int guarded(const char* where, F&& f) {
+    try { return f(); }
+    catch (const std::exception& e) { set_error(std::string(where) + ": " + e.what()); return -100; }
+    catch (...) { set_error(std::string(where) + ": unknown exception"); return -101; }
+}
+
+static void require_gpu() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw std::runtime_error("no HIP device: libladi_native has no CPU fallback");
+}
+
+// two-pass (plan, run) execution of a module graph on its own arena
+template <typename Body>
+static void run_planned(Arena& arena, float*& stats, size_t& stats_cap, hipStream_t st, Body&& body) {
+    for (int pass = 0; pass < 2; ++pass) {
+        arena.dry = (pass == 0);
+        arena.off = 0;
+        Ctx c; c.st = st; c.ar = &arena; c.stats = stats; c.stats_cap = stats_cap;
+        if (pass == 1 && stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
+        body(c);
+        if (pass == 0) {
+            arena.reserve(arena.peak + 4096);
+            if (c.stats_peak > stats_cap) {
+                if (stats) (void)hipFree(stats);
+                stats = nullptr;
+                HIP_OK(hipMalloc(reinterpret_cast<void**>(&stats), c.stats_peak * sizeof(float)));
+                stats_cap = c.stats_peak;
+            }
+        }
+    }
+}
+
+extern "C" {
+
+const char* ladi_last_error(void) { return last_error(); }
+int ladi_version(void) { return 100; }
+int ladi_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+// ------------------------------------------------------------------------------------------------ weights
+ladi_weights* ladi_weights_create(void) { return new (std::nothrow) ladi_weights(); }
+int ladi_weights_add(ladi_weights* w, const char* key, const void* data, int dtype, int ndim, const int64_t* shape) {
+    return guarded("ladi_weights_add", [&]() {
+        if (!w || !key || !data || ndim < 0 || ndim > 8) throw std::runtime_error("bad arguments");
+        HostTensor t;
+        t.shape.assign(shape, shape + ndim);
+        const size_t n = t.numel();
+        t.data.resize(n);
+        if (dtype == LADI_F32) std::memcpy(t.data.data(), data, n * 4);
+        else if (dtype == LADI_F16) { const _Float16* h = reinterpret_cast<const _Float16*>(data); for (size_t i = 0; i < n; ++i) t.data[i] = (float)h[i]; }
+        else throw std::runtime_error("unsupported dtype");
+        w->ws.m[key] = std::move(t);
+        return 0;
+    });
+}
+int ladi_weights_count(const ladi_weights* w) { return w ? (int)w->ws.m.size() : -1; }
+void ladi_weights_destroy(ladi_weights* w) { delete w; }
+
+// ------------------------------------------------------------------------------------------------ UNet
+ladi_unet* ladi_unet_create(const ladi_unet_config* cfg, const ladi_weights* ws) {
+    ladi_unet* h = nullptr;
+    int rc = guarded("ladi_unet_create", [&]() {
+        if (!cfg || !ws) throw std::runtime_error("null argument");
+        require_gpu();
+        UNetCfg c;
+        c.in_channels = cfg->in_channels; c.out_channels = cfg->out_channels;
+        for (int i = 0; i < 4; ++i) { c.boc[i] = cfg->block_out_channels[i]; c.heads[i] = cfg->num_heads[i]; }
+        c.layers_per_block = cfg->layers_per_block; c.cross_dim = cfg->cross_attention_dim; c.groups = cfg->norm_num_groups; c.eps = cfg->norm_eps;
+        if (c.in_channels > 64) throw std::runtime_error("in_channels > 64 unsupported");
+        h = new ladi_unet();
+        h->u.load(c, ws->ws);
+        return 0;
+    });
+    if (rc) { delete h; return nullptr; }
+    return h;
+}
+void ladi_unet_destroy(ladi_unet* u) { delete u; }
+
+int ladi_unet_set_context(ladi_unet* u, const void* ehs, int n, int L, void* stream) {
+    return guarded("ladi_unet_set_context", [&]() { return u->u.set_context(reinterpret_cast<const h16*>(ehs), n, L, S(stream)); });
+}
+
+int ladi_unet_forward(ladi_unet* u, const void* sample, int dtype, int n, int h, int w, float timestep, void* out, int out_dtype,
+                      void* stream) {
+    return guarded("ladi_unet_forward", [&]() {
+        UNet& U = u->u;
+        hipStream_t st = S(stream);
+        if (U.compute_temb(&timestep, 1, st)) return -1;
+        run_planned(U.arena, U.stats, U.stats_cap, st, [&](Ctx& c) {
+            Act x = c.new_act(n, h, w, 64);
+            if (!c.dry()) c.check(ladi_launch_nchw_to_nhwc(sample, dtype == LADI_F32, n, U.cfg.in_channels, h, w, x.p, 64, st), "nchw_to_nhwc");
+            Act eps = U.forward(c, x, U.temb_table, nullptr);
+            if (!c.dry()) c.check(ladi_launch_nhwc_to_nchw(eps.p, eps.ld, n, U.cfg.out_channels, h, w, out, out_dtype == LADI_F32, st), "nhwc_to_nchw");
+        });
+        return 0;
+    });
+}
+
+int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* avg_ms, void* stream) {
+    return guarded("ladi_unet_time_forward", [&]() {
+        UNet& U = u->u;
+        hipStream_t st = S(stream);
+        float t0 = 500.f;
+        if (U.compute_temb(&t0, 1, st)) return -1;
+        hipEvent_t e0, e1;
+        HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+        run_planned(U.arena, U.stats, U.stats_cap, st, [&](Ctx& c) {
+            Act x = c.new_act(n, h, w, 64);
+            if (!c.dry()) HIP_OK(hipMemsetAsync(x.p, 0, x.pixels() * 64 * sizeof(h16), st));
+            const size_t mk = c.ar->mark();
+            // warm-up
+            c.stats_off = 0; (void)U.forward(c, x, U.temb_table, nullptr); c.ar->release(mk);
+            if (!c.dry()) HIP_OK(hipEventRecord(e0, st));
+            for (int i = 0; i < (c.dry() ? 1 : iters); ++i) {
+                c.stats_off = 0;
+                if (!c.dry()) HIP_OK(hipMemsetAsync(c.stats, 0, c.stats_cap * sizeof(float), st));
+                (void)U.forward(c, x, U.temb_table, nullptr);
+                c.ar->release(mk);
+            }
+            if (!c.dry()) HIP_OK(hipEventRecord(e1, st));
+        });
+        HIP_OK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = ms / (float)iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        return 0;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ VAE
+ladi_vae* ladi_vae_create(const ladi_vae_config* cfg, const ladi_weights* ws) {
+    ladi_vae* h = nullptr;
+    int rc = guarded("ladi_vae_create", [&]() {
+        if (!cfg || !ws) throw std::runtime_error("null argument");
+        require_gpu();
+        VAECfg c;
+        c.in_channels = cfg->in_channels; c.out_channels = cfg->out_channels; c.latent_channels = cfg->latent_channels;
+        for (int i = 0; i < 4; ++i) c.boc[i] = cfg->block_out_channels[i];
+        c.layers_per_block = cfg->layers_per_block; c.groups = cfg->norm_num_groups; c.scaling_factor = cfg->scaling_factor;
+        if (c.latent_channels != 4 || c.in_channels != 3 || c.out_channels != 3) throw std::runtime_error("VAE: only 3->4->3 channels supported");
+        h = new ladi_vae();
+        h->v.load(c, ws->ws);
+        return 0;
+    });
+    if (rc) { delete h; return nullptr; }
+    return h;
+}
+void ladi_vae_destroy(ladi_vae* v) { delete v; }
+
+int ladi_vae_encode(ladi_vae* v, const void* x, int dtype, int B, int H, int W, float* moments, void* const* feats_out, void* stream) {
+    return guarded("ladi_vae_encode", [&]() {
+        VAE& V = v->v;
+        hipStream_t st = S(stream);
+        if (H % 8 || W % 8) throw std::runtime_error("H and W must be divisible by 8");
+        run_planned(V.arena, V.stats, V.stats_cap, st, [&](Ctx& c) {
+            Act xi = c.new_act(B, H, W, 64);
+            if (!c.dry()) c.check(ladi_launch_nchw_to_nhwc(x, dtype == LADI_F32, B, 3, H, W, xi.p, 64, st), "nchw_to_nhwc");
+            Act feats[5];
+            Act mom = V.encode(c, xi, feats);
+            if (c.dry()) return;
+            c.check(ladi_launch_nhwc_to_nchw(mom.p, mom.ld, B, 8, H / 8, W / 8, moments, 1, st), "moments");
+            if (feats_out)
+                for (int i = 0; i < 5; ++i)
+                    if (feats_out[i]) HIP_OK(hipMemcpyAsync(feats_out[i], feats[i].p, feats[i].pixels() * feats[i].c * sizeof(h16), hipMemcpyDeviceToDevice, st));
+        });
+        return 0;
+    });
+}
+
+int ladi_vae_decode(ladi_vae* v, const float* z, int B, int h, int w, const void* const* skips_dev, void* sample, int out_dtype,
+                    void* stream) {
+    return guarded("ladi_vae_decode", [&]() {
+        VAE& V = v->v;
+        hipStream_t st = S(stream);
+        run_planned(V.arena, V.stats, V.stats_cap, st, [&](Ctx& c) {
+            float* zp = c.alloc_f32((size_t)B * h * w * 4);
+            Act zi = c.new_act(B, h, w, 64);
+            Act skips[5];
+            if (skips_dev) {
+                const int H = 8 * h, W = 8 * w;
+                const int sh[5] = {H, H, H / 2, H / 4, H / 8}, sw[5] = {W, W, W / 2, W / 4, W / 8};
+                const int sc[5] = {V.cfg.boc[0], V.cfg.boc[1], V.cfg.boc[2], V.cfg.boc[3], V.cfg.boc[3]};
+                for (int i = 0; i < 5; ++i) {
+                    skips[i].p = reinterpret_cast<h16*>(const_cast<void*>(skips_dev[i]));
+                    skips[i].n = B; skips[i].h = sh[i]; skips[i].w = sw[i]; skips[i].c = sc[i]; skips[i].ld = sc[i];
+                }
+            }
+            if (!c.dry()) {
+                c.check(ladi_launch_lat_nchw_to_pix(z, B, h * w, 1.0f, zp, st), "z");
+                c.check(ladi_launch_post_quant(zp, V.d_pq, 1.0f, B * h * w, zi.p, 64, st), "post_quant");
+            }
+            Act img = V.decode(c, zi, skips_dev ? skips : nullptr);
+            if (!c.dry()) c.check(ladi_launch_nhwc_to_nchw(img.p, img.ld, B, 3, 8 * h, 8 * w, sample, out_dtype == LADI_F32, st), "sample");
+        });
+        return 0;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ EMASC
+ladi_emasc* ladi_emasc_create(const ladi_emasc_config* cfg, const ladi_weights* ws) {
+    ladi_emasc* h = nullptr;
+    int rc = guarded("ladi_emasc_create", [&]() {
+        if (!cfg || !ws) throw std::runtime_error("null argument");
+        require_gpu();
+        if (cfg->n < 1 || cfg->n > 8) throw std::runtime_error("EMASC: n out of range");
+        EMASCCfg c; c.n = cfg->n;
+        for (int i = 0; i < cfg->n; ++i) { c.in_ch[i] = cfg->in_channels[i]; c.out_ch[i] = cfg->out_channels[i]; }
+        h = new ladi_emasc();
+        h->e.load(c, ws->ws);
+        return 0;
+    });
+    if (rc) { delete h; return nullptr; }
+    return h;
+}
+void ladi_emasc_destroy(ladi_emasc* e) { delete e; }
+
+int ladi_emasc_forward(ladi_emasc* e, const void* const* feats_dev, const int* hs, const int* wss, int B, const void* mask_dev, int Hm,
+                       int Wm, void* const* outs_dev, void* stream) {
+    return guarded("ladi_emasc_forward", [&]() {
+        EMASC& E = e->e;
+        hipStream_t st = S(stream);
+        float* nostats = nullptr; size_t nocap = 0;
+        run_planned(E.arena, nostats, nocap, st, [&](Ctx& c) {
+            Act feats[8], outs[8];
+            const h16* masks[8];
+            for (int i = 0; i < E.cfg.n; ++i) {
+                feats[i].p = reinterpret_cast<h16*>(const_cast<void*>(feats_dev[i]));
+                feats[i].n = B; feats[i].h = hs[i]; feats[i].w = wss[i]; feats[i].c = E.cfg.in_ch[i]; feats[i].ld = E.cfg.in_ch[i];
+                outs[i] = feats[i]; outs[i].p = reinterpret_cast<h16*>(outs_dev[i]); outs[i].c = E.cfg.out_ch[i]; outs[i].ld = E.cfg.out_ch[i];
+                masks[i] = nullptr;
+                if (mask_dev) {
+                    const int s = Hm / hs[i];
+                    if (s * hs[i] != Hm || s * wss[i] != Wm) throw std::runtime_error("EMASC: mask size must be an integer multiple of each feature size");
+                    if (s == 1) masks[i] = reinterpret_cast<const h16*>(mask_dev);
+                    else {
+                        h16* m = c.alloc_h16((size_t)B * hs[i] * wss[i]);
+                        if (!c.dry()) c.check(ladi_launch_mask_down(reinterpret_cast<const h16*>(mask_dev), B, Hm, Wm, s, m, st), "mask_down");
+                        masks[i] = m;
+                    }
+                }
+            }
+            E.forward(c, feats, mask_dev ? masks : nullptr, outs, true);
+        });
+        return 0;
+    });
+}
+
+int ladi_mask_features(void* feat, int B, int h, int w, int C, const void* mask, int Hm, int Wm, void* stream) {
+    return guarded("ladi_mask_features", [&]() {
+        hipStream_t st = S(stream);
+        const int s = Hm / h;
+        if (s * h != Hm || s * w != Wm) throw std::runtime_error("mask size must be an integer multiple of the feature size");
+        const h16* m = reinterpret_cast<const h16*>(mask);
+        h16* tmp = nullptr;
+        if (s != 1) {
+            HIP_OK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (size_t)B * h * w * sizeof(h16), st));
+            int rc = ladi_launch_mask_down(m, B, Hm, Wm, s, tmp, st);
+            if (rc) return rc;
+            m = tmp;
+        }
+        int rc = ladi_launch_mask_mul(reinterpret_cast<h16*>(feat), C, B * h * w, m, st);
+        if (tmp) HIP_OK(hipFreeAsync(tmp, st));
+        return rc;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ adapter
+ladi_adapter* ladi_adapter_create(const ladi_adapter_config* cfg, const ladi_weights* ws) {
+    ladi_adapter* h = nullptr;
+    int rc = guarded("ladi_adapter_create", [&]() {
+        if (!cfg || !ws) throw std::runtime_error("null argument");
+        require_gpu();
+        AdapterCfg c; c.hidden = cfg->hidden; c.heads = cfg->heads; c.mlp = cfg->mlp_dim; c.head_hidden = cfg->head_hidden; c.out_dim = cfg->out_dim;
+        c.ln_eps = cfg->layer_norm_eps;
+        if (c.hidden % 64 || c.hidden / c.heads > 128) throw std::runtime_error("adapter: hidden must be a multiple of 64 and head dim <= 128");
+        h = new ladi_adapter();
+        h->a.load(c, ws->ws);
+        return 0;
+    });
+    if (rc) { delete h; return nullptr; }
+    return h;
+}
+void ladi_adapter_destroy(ladi_adapter* a) { delete a; }
+int ladi_adapter_forward(ladi_adapter* a, const void* x, int B, int T, void* out, void* stream) {
+    return guarded("ladi_adapter_forward", [&]() { return a->a.forward(reinterpret_cast<const h16*>(x), B, T, reinterpret_cast<h16*>(out), S(stream)); });
+}
+
+// ------------------------------------------------------------------------------------------------ scheduler helpers
+int ladi_sched_timesteps(int kind, int steps, int* out, int cap) {
+    return guarded("ladi_sched_timesteps", [&]() {
+        if (steps < 2 || steps > 1000) throw std::runtime_error("num_inference_steps out of range");
+        std::vector<float> ac; default_alphas_cumprod(ac);
+        std::vector<int> ts; std::vector<StepTable> tb;
+        build_step_table(kind, steps, ac.data(), 1.0f, ts, tb);
+        if ((int)ts.size() > cap) throw std::runtime_error("timesteps buffer too small");
+        for (size_t i = 0; i < ts.size(); ++i) out[i] = ts[i];
+        return (int)ts.size();
+    });
+}
+int ladi_sched_alphas_cumprod(float* out) {
+    std::vector<float> ac; default_alphas_cumprod(ac);
+    std::memcpy(out, ac.data(), 1000 * sizeof(float));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ try-on
+ladi_tryon* ladi_tryon_create(ladi_unet* unet, ladi_vae* vae, ladi_emasc* emasc) {
+    if (!unet || !vae) { set_error("ladi_tryon_create: unet and vae required"); return nullptr; }
+    ladi_tryon* t = new (std::nothrow) ladi_tryon();
+    if (!t) return nullptr;
+    t->t.unet = &unet->u; t->t.vae = &vae->v; t->t.emasc = emasc ? &emasc->e : nullptr;
+    return t;
+}
+void ladi_tryon_destroy(ladi_tryon* t) { delete t; }
+int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images, float* latents, void* stream) {
+    return guarded("ladi_tryon_run", [&]() {
+        if (!t || !in || !images) throw std::runtime_error("null argument");
+        TryOnInputs ti;
+        ti.batch = in->batch; ti.height = in->height; ti.width = in->width; ti.in_f32 = in->in_dtype == LADI_F32;
+        ti.image = in->image_dev; ti.mask_image = in->mask_image_dev; ti.pose_map = in->pose_map_dev; ti.warped_cloth = in->warped_cloth_dev;
+        ti.pose_channels = in->pose_channels;
+        ti.prompt_embeds = reinterpret_cast<const h16*>(in->prompt_embeds_dev);
+        ti.negative_prompt_embeds = reinterpret_cast<const h16*>(in->negative_prompt_embeds_dev);
+        ti.L = in->L;
+        ti.noise_cloth = in->noise_cloth_dev; ti.noise_latents = in->noise_latents_dev; ti.noise_masked = in->noise_masked_dev;
+        ti.steps = in->num_inference_steps; ti.guidance = in->guidance_scale; ti.scheduler = in->scheduler;
+        ti.cloth_cond_rate = in->cloth_cond_rate; ti.no_pose = in->no_pose; ti.use_graph = in->use_graph;
+        ti.alphas_cumprod = in->alphas_cumprod_host;
+        if (ti.steps < 2 || ti.steps > 1000) throw std::runtime_error("num_inference_steps out of range");
+        if (!ti.image || !ti.mask_image || !ti.pose_map || !ti.prompt_embeds || !ti.noise_latents || !ti.noise_masked) throw std::runtime_error("missing input");
+        if (ti.warped_cloth && !ti.noise_cloth) throw std::runtime_error("noise_cloth required with warped_cloth");
+        return t->t.run(ti, images, latents, S(stream));
+    });
+}
+int ladi_tryon_stage_ms(ladi_tryon* t, float* out3) { return t ? t->t.stage_ms(out3) : -1; }
+
+// ------------------------------------------------------------------------------------------------ op level
+int ladi_op_igemm(const ladi_igemm_desc* d, int batch, int tile_cfg, void* stream) {
+    return guarded("ladi_op_igemm", [&]() {
+        IGemmArgs a;
+        std::memcpy(&a, d, sizeof(a));
+        int rc = ladi_launch_igemm(a, batch, tile_cfg, S(stream));
+        if (rc) set_error("igemm launch rc=" + std::to_string(rc));
+        return rc;
+    });
+}
+int ladi_op_group_norm(const void* src0, int C0, const void* src1, int C1, int n, int HW, int groups, const void* gamma, const void* beta,
+                       float eps, int silu, const void* add, void* out, float* stats, void* stream) {
+    return guarded("ladi_op_group_norm", [&]() {
+        hipStream_t st = S(stream);
+        HIP_OK(hipMemsetAsync(stats, 0, (size_t)n * groups * 2 * sizeof(float), st));
+        int rc = ladi_launch_gn_stats((const h16*)src0, C0, C0, (const h16*)src1, C1, C1, n, HW, groups, stats, st);
+        if (!rc) rc = ladi_launch_gn_apply((const h16*)src0, C0, C0, (const h16*)src1, C1, C1, n, HW, groups, stats, (const h16*)gamma,
+                                           (const h16*)beta, eps, silu, (const h16*)add, (h16*)out, st);
+        return rc;
+    });
+}
+int ladi_op_layer_norm(const void* x, const void* gamma, const void* beta, float eps, int rows, int C, void* out, void* stream) {
+    return ladi_launch_layernorm((const h16*)x, C, (const h16*)gamma, (const h16*)beta, eps, rows, C, (h16*)out, C, S(stream));
+}
+int ladi_op_attention(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq, long long sk,
+                      long long sv, long long so, int n, int heads, int Nq, int Nk, float scale, void* stream) {
+    AttnArgs a;
+    a.q = (const h16*)q; a.k = (const h16*)k; a.v = (const h16*)v; a.o = (h16*)o;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.sq = sq; a.sk = sk; a.sv = sv; a.so = so;
+    a.n = n; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    return ladi_launch_flash_attn64(a, S(stream));
+}
+int ladi_op_softmax_rows(const float* Sm, int rows, int cols, float scale, void* P, void* stream) {
+    return ladi_launch_softmax_rows(Sm, rows, cols, scale, (h16*)P, S(stream));
+}
+int ladi_op_small_linear(const void* x, int x_f32, int ldx, const void* W, const void* bias, const void* res, int ldr, int M, int N, int K,
+                         int act, int pre_silu, void* out, int out_f32, int ldo, void* stream) {
+    return ladi_launch_small_linear(x, x_f32, ldx, (const h16*)W, (const h16*)bias, (const h16*)res, ldr, M, N, K, act, pre_silu, out,
+                                    out_f32, ldo, S(stream));
+}
+int ladi_op_nchw_to_nhwc(const void* src, int dtype, int n, int C, int H, int W, void* dst, int ld, void* stream) {
+    return ladi_launch_nchw_to_nhwc(src, dtype == LADI_F32, n, C, H, W, (h16*)dst, ld, S(stream));
+}
+int ladi_op_nhwc_to_nchw(const void* src, int ld, int n, int C, int H, int W, void* dst, int dtype, void* stream) {
+    return ladi_launch_nhwc_to_nchw((const h16*)src, ld, n, C, H, W, dst, dtype == LADI_F32, S(stream));
+}
+int ladi_op_sched_run(int kind, int steps, const float* ac_host, const void* eps_seq, int evals, int B, int hw, int cfg, float guidance,
+                      float* latents, void* stream) {
+    return guarded("ladi_op_sched_run", [&]() {
+        hipStream_t st = S(stream);
+        std::vector<float> ac;
+        if (ac_host) ac.assign(ac_host, ac_host + 1000); else default_alphas_cumprod(ac);
+        std::vector<int> ts; std::vector<StepTable> tb;
+        build_step_table(kind, steps, ac.data(), 1.0f, ts, tb);
+        if (evals > (int)tb.size()) throw std::runtime_error("evals exceeds scheduler length");
+        char* buf = nullptr;
+        const size_t plane = (size_t)B * hw * 4 * sizeof(float);
+        const size_t tb_bytes = (tb.size() * sizeof(StepTable) + 255) & ~(size_t)255;
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&buf), tb_bytes + 256 + 5 * plane));
+        StepTable* dt = reinterpret_cast<StepTable*>(buf);
+        int* dstep = reinterpret_cast<int*>(buf + tb_bytes);
+        float* cur = reinterpret_cast<float*>(buf + tb_bytes + 256);
+        float* ets = cur + (size_t)B * hw * 4;
+        HIP_OK(hipMemcpyAsync(dt, tb.data(), tb.size() * sizeof(StepTable), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(dstep, 0, 4, st));
+        const int rows = (cfg ? 2 : 1) * B * hw;
+        int rc = 0;
+        for (int i = 0; i < evals && !rc; ++i) {
+            StepArgs sa; std::memset(&sa, 0, sizeof(sa));
+            sa.eps = reinterpret_cast<const h16*>(eps_seq) + (size_t)i * rows * 4; sa.ld_eps = 4;
+            sa.B = B; sa.hw = hw; sa.cfg = cfg; sa.guidance = guidance; sa.latents = latents; sa.cur_sample = cur; sa.ets = ets;
+            sa.table = dt; sa.step_idx = dstep; sa.unet_in = nullptr;
+            rc = ladi_launch_sched_step(sa, st);
+        }
+        HIP_OK(hipStreamSynchronize(st));
+        (void)hipFree(buf);
+        return rc;
+    });
+}
+
+}  // extern "C"

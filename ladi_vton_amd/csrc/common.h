@@ -1,0 +1,76 @@
+// Common device/host definitions for libladi_native (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef _Float16 h16;
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LADI_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// Activation codes shared by kernels
+// ---------------------------------------------------------------------------------------------
+enum {
+    LADI_ACT_NONE = 0,
+    LADI_ACT_SILU = 1,
+    LADI_ACT_GELU = 2,   // exact erf GELU
+    LADI_ACT_GEGLU = 3   // igemm only: rows interleaved in blocks of 32 (u | g), out = u * gelu(g)
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM argument block (conv3x3 / conv1x1 / linear / batched GEMM), see igemm.hip
+// ---------------------------------------------------------------------------------------------
+struct IGemmArgs {
+    // "pixel" operand: up to two NHWC fp16 sources concatenated along channels (C1 = 0 -> single)
+    const h16* src0; const h16* src1;
+    int C0, C1;          // channels taken from each source (multiples of 64)
+    int ld0, ld1;        // row (pixel) stride of each source in elements
+    int Hs, Ws;          // physical source spatial size (per sample)
+    int Ho, Wo;          // output spatial size (per sample)
+    int P;               // number of output pixels = n * Ho * Wo
+    int ksize;           // 1 or 3
+    int stride;          // 1 or 2
+    int pad;             // leading pad (top/left); trailing pad is implied by bounds check
+    int ups;             // 1: nearest-2x upsample folded into the gather (source is Hs x Ws, logical 2Hs x 2Ws)
+    // "weight" operand: [Q][K] fp16 row-major, K = ksize*ksize*(C0+C1), tap-major / channel-minor
+    const h16* W;
+    int Q;               // output channels (rows of W)
+    int K;
+    int ldw;             // row stride of W in elements (0 -> K)
+    // batching over grid.z (element strides); 0 = shared
+    long long bs_src0, bs_w, bs_out, bs_res;
+    // epilogue
+    const h16* bias;     // [Q] or null (GEGLU: interleaved like W rows)
+    int bias_per_pixel;  // 1: bias indexed by pixel (row-bias for transposed products)
+    const float* rowadd; // [Q] fp32 added per output channel (time embedding) or null
+    const int* rowadd_idx; int rowadd_stride; // optional device-side row selector: rowadd + (*idx)*stride
+    int act;
+    float out_scale;
+    const h16* res0; const h16* res1; // residual tensors [P][ldr] or null
+    int ldr0, ldr1;
+    const h16* mask;     // [P] fp16; out *= (1 - mask[p]) or null
+    void* out; int ldo;  // [P][ldo]
+    int out_f32;         // 1: store fp32
+    float* stats;        // optional GroupNorm partial sums of the OUTPUT: [n][groups][2] (sum, sumsq), atomics
+    int stats_groups;    // number of groups (channels per group = Qout / groups)
+};

@@ -1,0 +1,441 @@
+// HBM-bound / tiny kernels of the try-on hot path: layout conversion at the NCHW boundary, small-M
+// weight-streaming linear (time embedding, inversion-adapter head), the fused CFG + DDIM/PLMS scheduler
+// step + next-UNet-input assembly, posterior sampling, mask / pose resizes.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// small-M linear: one wave per output column, MT rows of x per pass. W [N][K] fp16 (K % 8 == 0).
+// ------------------------------------------------------------------------------------------------
+template <typename XT, int MT>
+__global__ __launch_bounds__(256) void small_linear_kernel(const XT* __restrict__ x, int ldx, const h16* __restrict__ W,
+                                                           const h16* __restrict__ bias, const h16* __restrict__ res, int ldr,
+                                                           int M, int N, int K, int act, int pre_silu, void* __restrict__ out,
+                                                           int out_f32, int ldo) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nn = blockIdx.x * 4 + wave;
+    const int m0 = blockIdx.y * MT;
+    if (nn >= N) return;
+    float acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = 0.f;
+    const h16* wrow = W + (size_t)nn * K;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        const h16x8 w = *reinterpret_cast<const h16x8*>(wrow + k);
+        float wf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wf[e] = (float)w[e];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + i;
+            if (m < M) {
+                const XT* xr = x + (size_t)m * ldx + k;
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xv = (float)xr[e];
+                    if (pre_silu) xv = silu_f(xv);
+                    s += xv * wf[e];
+                }
+                acc[i] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float s = wave_sum(acc[i]);
+        const int m = m0 + i;
+        if (lane == 0 && m < M) {
+            if (bias) s += (float)bias[nn];
+            if (act == LADI_ACT_SILU) s = silu_f(s);
+            else if (act == LADI_ACT_GELU) s = gelu_f(s);
+            if (res) s += (float)res[(size_t)m * ldr + nn];
+            if (out_f32) reinterpret_cast<float*>(out)[(size_t)m * ldo + nn] = s;
+            else reinterpret_cast<h16*>(out)[(size_t)m * ldo + nn] = (h16)s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NCHW (fp32/fp16) -> NHWC fp16 with channel padding to ld (zeros); LDS-tiled transpose over (C, W)
+// ------------------------------------------------------------------------------------------------
+template <typename ST>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const ST* __restrict__ src, int C, int HW, h16* __restrict__ dst,
+                                                           int ld) {
+    // block handles 64 pixels x all channels (in chunks of 64 channels)
+    __shared__ h16 tile[64][65];
+    const int n = blockIdx.y;
+    const int pix0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty 0..3
+    for (int c0 = 0; c0 < ld; c0 += 64) {
+        for (int cc = ty; cc < 64; cc += 4) {
+            const int c = c0 + cc, pix = pix0 + tx;
+            h16 v = (h16)0.f;
+            if (c < C && pix < HW) v = (h16)(float)src[((size_t)n * C + c) * HW + pix];
+            tile[cc][tx] = v;
+        }
+        __syncthreads();
+        for (int pp = ty; pp < 64; pp += 4) {
+            const int pix = pix0 + pp, c = c0 + tx;
+            if (pix < HW && c < ld) dst[((size_t)n * HW + pix) * ld + c] = tile[tx][pp];
+        }
+        __syncthreads();
+    }
+}
+
+template <typename DT>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const h16* __restrict__ src, int ld, int C, int HW,
+                                                           DT* __restrict__ dst) {
+    __shared__ h16 tile[64][65];
+    const int n = blockIdx.y;
+    const int pix0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        for (int pp = ty; pp < 64; pp += 4) {
+            const int pix = pix0 + pp, c = c0 + tx;
+            h16 v = (h16)0.f;
+            if (pix < HW && c < C) v = src[((size_t)n * HW + pix) * ld + c];
+            tile[pp][tx] = v;
+        }
+        __syncthreads();
+        for (int cc = ty; cc < 64; cc += 4) {
+            const int c = c0 + cc, pix = pix0 + tx;
+            if (c < C && pix < HW) dst[((size_t)n * C + c) * HW + pix] = (DT)(float)tile[tx][cc];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int count, int dim, float* __restrict__ out) {
+    const int i = blockIdx.x, j = threadIdx.x + blockIdx.y * blockDim.x;
+    const int half = dim / 2;
+    if (i >= count || j >= half) return;
+    const float freq = __expf(-9.210340371976184f * (float)j / (float)half);  // ln(10000)
+    const float arg = t[i] * freq;
+    // flip_sin_to_cos: [cos | sin]
+    out[(size_t)i * dim + j] = cosf(arg);
+    out[(size_t)i * dim + half + j] = sinf(arg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused CFG combine + scheduler update (DDIM or PLMS table entry) + UNet-input refresh
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sched_step_kernel(const StepArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // (b, pixel)
+    const int total = a.B * a.hw;
+    if (idx >= total) return;
+    const StepTable T = a.table[*a.step_idx];
+    const int b = idx / a.hw;
+    const size_t row_u = (size_t)idx;                       // uncond (or only) row
+    const size_t row_c = (size_t)idx + (size_t)total;       // cond row when cfg
+    float e[4];
+    {
+        const h16x4 eu = *reinterpret_cast<const h16x4*>(a.eps + row_u * a.ld_eps);
+        if (a.cfg) {
+            const h16x4 ec = *reinterpret_cast<const h16x4*>(a.eps + row_c * a.ld_eps);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { float u = (float)eu[c]; e[c] = u + a.guidance * ((float)ec[c] - u); }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) e[c] = (float)eu[c];
+        }
+    }
+    (void)b;
+    const size_t plane = (size_t)total * 4;
+    float4 x = reinterpret_cast<const float4*>(a.latents)[idx];
+    if (T.save_cur) reinterpret_cast<float4*>(a.cur_sample)[idx] = x;
+    if (T.mode == 1) x = reinterpret_cast<const float4*>(a.cur_sample)[idx];
+    float ec[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ec[c] = T.w[0] * e[c];
+    // history slots are encoded in the table through w[] order: slot ids packed in push field's upper bits
+    const int s1 = (T.push >> 8) & 3, s2 = (T.push >> 10) & 3, s3 = (T.push >> 12) & 3, sp = (T.push >> 4) & 3;
+    if (T.w[1] != 0.f) { const float4 h = reinterpret_cast<const float4*>(a.ets + s1 * plane)[idx];
+        ec[0] += T.w[1] * h.x; ec[1] += T.w[1] * h.y; ec[2] += T.w[1] * h.z; ec[3] += T.w[1] * h.w; }
+    if (T.w[2] != 0.f) { const float4 h = reinterpret_cast<const float4*>(a.ets + s2 * plane)[idx];
+        ec[0] += T.w[2] * h.x; ec[1] += T.w[2] * h.y; ec[2] += T.w[2] * h.z; ec[3] += T.w[2] * h.w; }
+    if (T.w[3] != 0.f) { const float4 h = reinterpret_cast<const float4*>(a.ets + s3 * plane)[idx];
+        ec[0] += T.w[3] * h.x; ec[1] += T.w[3] * h.y; ec[2] += T.w[3] * h.z; ec[3] += T.w[3] * h.w; }
+    if (T.push & 1) reinterpret_cast<float4*>(a.ets + sp * plane)[idx] = make_float4(e[0], e[1], e[2], e[3]);
+    float4 xn;
+    xn.x = T.c_x * x.x + T.c_e * ec[0]; xn.y = T.c_x * x.y + T.c_e * ec[1];
+    xn.z = T.c_x * x.z + T.c_e * ec[2]; xn.w = T.c_x * x.w + T.c_e * ec[3];
+    reinterpret_cast<float4*>(a.latents)[idx] = xn;
+    if (a.unet_in) {
+        h16x4 o; o[0] = (h16)xn.x; o[1] = (h16)xn.y; o[2] = (h16)xn.z; o[3] = (h16)xn.w;
+        *reinterpret_cast<h16x4*>(a.unet_in + row_u * a.ld_in) = o;
+        if (a.cfg) *reinterpret_cast<h16x4*>(a.unet_in + row_c * a.ld_in) = o;
+        if (T.zero_cloth_next) {
+            h16x4 zz = {0, 0, 0, 0};
+            // cloth channels are not 8-byte aligned (27..30): scalar stores
+            h16* pu = a.unet_in + row_u * a.ld_in + a.cloth_ch0;
+            pu[0] = zz[0]; pu[1] = zz[1]; pu[2] = zz[2]; pu[3] = zz[3];
+            if (a.cfg) { h16* pc = a.unet_in + row_c * a.ld_in + a.cloth_ch0; pc[0] = zz[0]; pc[1] = zz[1]; pc[2] = zz[2]; pc[3] = zz[3]; }
+        }
+    }
+}
+__global__ void bump_counter_kernel(int* p) { *p = *p + 1; }
+
+__global__ __launch_bounds__(256) void assemble_static_kernel(h16* __restrict__ unet_in, int ld_in, int B, int hw, int cfg,
+                                                              const float* __restrict__ latents,
+                                                              const h16* __restrict__ mask_lat,
+                                                              const float* __restrict__ masked_lat,
+                                                              const h16* __restrict__ pose, int pose_ch,
+                                                              const float* __restrict__ cloth_lat, int has_cloth) {
+    const int rows = (cfg ? 2 : 1) * B * hw;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const int total = B * hw;
+    const bool cond = cfg ? (row >= total) : true;
+    const int src = cfg ? (row % total) : row;
+    h16* o = unet_in + (size_t)row * ld_in;
+    int c = 0;
+    for (int i = 0; i < 4; ++i) o[c++] = (h16)latents[(size_t)src * 4 + i];
+    o[c++] = mask_lat[src];
+    for (int i = 0; i < 4; ++i) o[c++] = (h16)masked_lat[(size_t)src * 4 + i];
+    for (int i = 0; i < pose_ch; ++i) o[c++] = cond ? pose[(size_t)src * pose_ch + i] : (h16)0.f;
+    if (has_cloth) for (int i = 0; i < 4; ++i) o[c++] = cond ? (h16)cloth_lat[(size_t)src * 4 + i] : (h16)0.f;
+    for (; c < ld_in; ++c) o[c] = (h16)0.f;
+}
+
+__global__ __launch_bounds__(256) void posterior_sample_kernel(const h16* __restrict__ moments, int ldm,
+                                                               const float* __restrict__ noise, int B, int hw, float scaling,
+                                                               float* __restrict__ lat) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * hw) return;
+    const int b = idx / hw, p = idx - b * hw;
+    const h16* m = moments + (size_t)idx * ldm;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float mean = (float)m[c];
+        float lv = fminf(fmaxf((float)m[4 + c], -30.f), 20.f);
+        const float std = __expf(0.5f * lv);
+        const float nz = noise ? noise[((size_t)b * 4 + c) * hw + p] : 0.f;
+        lat[(size_t)idx * 4 + c] = (mean + std * nz) * scaling;
+    }
+}
+
+template <typename IT, typename MT>
+__global__ __launch_bounds__(256) void prepare_mask_kernel(const IT* __restrict__ image, const MT* __restrict__ mask, int B,
+                                                           int HW, h16* __restrict__ masked_img, int ld,
+                                                           h16* __restrict__ mask_bin) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * HW) return;
+    const int b = idx / HW, p = idx - b * HW;
+    const float mv = (float)mask[idx];
+    const float mb = mv >= 0.5f ? 1.f : 0.f;
+    mask_bin[idx] = (h16)mb;
+    h16* o = masked_img + (size_t)idx * ld;
+    for (int c = 0; c < 3; ++c) {
+        const float v = (float)image[((size_t)b * 3 + c) * HW + p];
+        o[c] = (h16)(mb < 0.5f ? v : 0.f);
+    }
+    for (int c = 3; c < ld; ++c) o[c] = (h16)0.f;
+}
+
+__global__ void mask_down_kernel(const h16* __restrict__ src, int B, int H, int W, int s, h16* __restrict__ dst) {
+    const int h = H / s, w = W / s;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * h * w) return;
+    const int b = idx / (h * w), r = idx - b * h * w, y = r / w, x = r - y * w;
+    dst[idx] = src[((size_t)b * H + y * s) * W + x * s];
+}
+
+template <typename PT>
+__global__ void pose_down8_kernel(const PT* __restrict__ pose, int B, int C, int H, int W, h16* __restrict__ dst) {
+    const int h = H / 8, w = W / 8;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (b, y, x, c)
+    if (idx >= B * h * w * C) return;
+    const int c = idx % C, r = idx / C, x = r % w, y = (r / w) % h, b = r / (w * h);
+    const PT* p = pose + ((size_t)b * C + c) * H * W;
+    const int y0 = 8 * y + 3, x0 = 8 * x + 3;
+    const float v = 0.25f * ((float)p[(size_t)y0 * W + x0] + (float)p[(size_t)y0 * W + x0 + 1] +
+                             (float)p[(size_t)(y0 + 1) * W + x0] + (float)p[(size_t)(y0 + 1) * W + x0 + 1]);
+    dst[idx] = (h16)v;
+}
+
+__global__ void image_post_kernel(const h16* __restrict__ src, int ld, int n_pix, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pix) return;
+    const h16* s = src + (size_t)idx * ld;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[(size_t)idx * 3 + c] = fminf(fmaxf((float)s[c] * 0.5f + 0.5f, 0.f), 1.f);
+}
+
+__global__ __launch_bounds__(256) void mask_mul_kernel(h16* __restrict__ feat, int C, int n_pix, const h16* __restrict__ mask) {
+    const size_t octs = (size_t)(C >> 3);
+    const size_t total = (size_t)n_pix * octs;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / octs;
+        const float mk = 1.f - (float)mask[pix];
+        h16x8 v = reinterpret_cast<h16x8*>(feat)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] * mk);
+        reinterpret_cast<h16x8*>(feat)[i] = v;
+    }
+}
+
+__global__ void fill_f32_kernel(float* p, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// z' = post_quant_conv(lat * inv_sf) (4x4 1x1 conv + bias; pq = 16 weights + 4 biases), written NHWC padded to ld
+__global__ void post_quant_kernel(const float* __restrict__ lat, const float* __restrict__ pq, float inv_sf, int n,
+                                  h16* __restrict__ dst, int ld) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float4 v = reinterpret_cast<const float4*>(lat)[idx];
+    const float z[4] = {v.x * inv_sf, v.y * inv_sf, v.z * inv_sf, v.w * inv_sf};
+    h16* o = dst + (size_t)idx * ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float s = pq ? pq[16 + c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (pq ? pq[c * 4 + j] : (c == j ? 1.f : 0.f)) * z[j];
+        o[c] = (h16)s;
+    }
+    for (int c = 4; c < ld; ++c) o[c] = (h16)0.f;
+}
+
+// fp32 latents NCHW [B][4][hw] <-> pixel-major [B][hw][4]
+__global__ void lat_nchw_to_pix_kernel(const float* __restrict__ src, int B, int hw, float scale, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * hw) return;
+    const int b = idx / hw, p = idx - b * hw;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[(size_t)idx * 4 + c] = src[((size_t)b * 4 + c) * hw + p] * scale;
+}
+__global__ void lat_pix_to_nchw_kernel(const float* __restrict__ src, int B, int hw, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * hw) return;
+    const int b = idx / hw, p = idx - b * hw;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[((size_t)b * 4 + c) * hw + p] = src[(size_t)idx * 4 + c];
+}
+
+inline int ok() { return hipGetLastError() == hipSuccess ? 0 : -11; }
+
+}  // namespace
+
+int ladi_launch_small_linear(const void* x, int x_f32, int ldx, const h16* W, const h16* bias, const h16* res, int ldr, int M,
+                             int N, int K, int act, int pre_silu, void* out, int out_f32, int ldo, hipStream_t st) {
+    if ((K & 7) || (ldx & 7)) return -1;
+    constexpr int MT = 8;
+    dim3 grid((N + 3) / 4, (M + MT - 1) / MT);
+    if (x_f32)
+        hipLaunchKernelGGL((small_linear_kernel<float, MT>), grid, dim3(256), 0, st, (const float*)x, ldx, W, bias, res, ldr, M, N, K,
+                           act, pre_silu, out, out_f32, ldo);
+    else
+        hipLaunchKernelGGL((small_linear_kernel<h16, MT>), grid, dim3(256), 0, st, (const h16*)x, ldx, W, bias, res, ldr, M, N, K,
+                           act, pre_silu, out, out_f32, ldo);
+    return ok();
+}
+
+int ladi_launch_nchw_to_nhwc(const void* src, int src_f32, int n, int C, int H, int W, h16* dst, int ld, hipStream_t st) {
+    dim3 grid((H * W + 63) / 64, n);
+    if (src_f32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, st, (const float*)src, C, H * W, dst, ld);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<h16>, grid, dim3(256), 0, st, (const h16*)src, C, H * W, dst, ld);
+    return ok();
+}
+
+int ladi_launch_nhwc_to_nchw(const h16* src, int ld, int n, int C, int H, int W, void* dst, int dst_f32, hipStream_t st) {
+    dim3 grid((H * W + 63) / 64, n);
+    if (dst_f32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, st, src, ld, C, H * W, (float*)dst);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<h16>, grid, dim3(256), 0, st, src, ld, C, H * W, (h16*)dst);
+    return ok();
+}
+
+int ladi_launch_timestep_embedding(const float* t, int count, int dim, float* out, hipStream_t st) {
+    const int half = dim / 2;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(count, (half + 63) / 64), dim3(64), 0, st, t, count, dim, out);
+    return ok();
+}
+
+int ladi_launch_sched_step(const StepArgs& a, hipStream_t st) {
+    const int total = a.B * a.hw;
+    hipLaunchKernelGGL(sched_step_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, a.step_idx);
+    return ok();
+}
+
+int ladi_launch_assemble_static(h16* unet_in, int ld_in, int B, int hw, int cfg, const float* latents, const h16* mask_lat,
+                                const float* masked_lat, const h16* pose, int pose_ch, const float* cloth_lat, int has_cloth,
+                                hipStream_t st) {
+    const int rows = (cfg ? 2 : 1) * B * hw;
+    if (9 + pose_ch + (has_cloth ? 4 : 0) > ld_in) return -1;
+    hipLaunchKernelGGL(assemble_static_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, unet_in, ld_in, B, hw, cfg, latents,
+                       mask_lat, masked_lat, pose, pose_ch, cloth_lat, has_cloth);
+    return ok();
+}
+
+int ladi_launch_posterior_sample(const h16* moments, int ldm, const float* noise_nchw, int B, int hw, float scaling, float* lat,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(posterior_sample_kernel, dim3((B * hw + 255) / 256), dim3(256), 0, st, moments, ldm, noise_nchw, B, hw,
+                       scaling, lat);
+    return ok();
+}
+
+int ladi_launch_prepare_mask(const void* image_nchw, int img_f32, const void* mask_nchw, int mask_f32, int B, int H, int W,
+                             h16* masked_img, int ld, h16* mask_bin, hipStream_t st) {
+    dim3 grid((B * H * W + 255) / 256);
+    const int HW = H * W;
+    if (img_f32 && mask_f32)
+        hipLaunchKernelGGL((prepare_mask_kernel<float, float>), grid, dim3(256), 0, st, (const float*)image_nchw,
+                           (const float*)mask_nchw, B, HW, masked_img, ld, mask_bin);
+    else if (img_f32)
+        hipLaunchKernelGGL((prepare_mask_kernel<float, h16>), grid, dim3(256), 0, st, (const float*)image_nchw,
+                           (const h16*)mask_nchw, B, HW, masked_img, ld, mask_bin);
+    else if (mask_f32)
+        hipLaunchKernelGGL((prepare_mask_kernel<h16, float>), grid, dim3(256), 0, st, (const h16*)image_nchw,
+                           (const float*)mask_nchw, B, HW, masked_img, ld, mask_bin);
+    else
+        hipLaunchKernelGGL((prepare_mask_kernel<h16, h16>), grid, dim3(256), 0, st, (const h16*)image_nchw,
+                           (const h16*)mask_nchw, B, HW, masked_img, ld, mask_bin);
+    return ok();
+}
+
+int ladi_launch_mask_down(const h16* src, int B, int H, int W, int s, h16* dst, hipStream_t st) {
+    const int total = B * (H / s) * (W / s);
+    hipLaunchKernelGGL(mask_down_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, B, H, W, s, dst);
+    return ok();
+}
+
+int ladi_launch_pose_down8(const void* pose_nchw, int f32, int B, int C, int H, int W, h16* dst, hipStream_t st) {
+    const int total = B * (H / 8) * (W / 8) * C;
+    if (f32) hipLaunchKernelGGL(pose_down8_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)pose_nchw, B,
+                                C, H, W, dst);
+    else hipLaunchKernelGGL(pose_down8_kernel<h16>, dim3((total + 255) / 256), dim3(256), 0, st, (const h16*)pose_nchw, B, C, H,
+                            W, dst);
+    return ok();
+}
+
+int ladi_launch_image_post(const h16* src, int ld, int n_pix, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(image_post_kernel, dim3((n_pix + 255) / 256), dim3(256), 0, st, src, ld, n_pix, dst);
+    return ok();
+}
+
+int ladi_launch_mask_mul(h16* feat, int C, int n_pix, const h16* mask, hipStream_t st) {
+    if (C & 7) return -1;
+    hipLaunchKernelGGL(mask_mul_kernel, dim3(2048), dim3(256), 0, st, feat, C, n_pix, mask);
+    return ok();
+}
+
+int ladi_launch_fill_f32(float* p, size_t n, float v, hipStream_t st) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(256), dim3(256), 0, st, p, n, v);
+    return ok();
+}
+
+int ladi_launch_post_quant(const float* lat, const float* pq, float inv_sf, int n, h16* dst, int ld, hipStream_t st) {
+    hipLaunchKernelGGL(post_quant_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lat, pq, inv_sf, n, dst, ld);
+    return ok();
+}
+int ladi_launch_lat_nchw_to_pix(const float* src, int B, int hw, float scale, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(lat_nchw_to_pix_kernel, dim3((B * hw + 255) / 256), dim3(256), 0, st, src, B, hw, scale, dst);
+    return ok();
+}
+int ladi_launch_lat_pix_to_nchw(const float* src, int B, int hw, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(lat_pix_to_nchw_kernel, dim3((B * hw + 255) / 256), dim3(256), 0, st, src, B, hw, dst);
+    return ok();
+}

@@ -1,0 +1,92 @@
+// Host-side launch prototypes of every HIP kernel in libladi_native (internal header).
+// All activations are NHWC fp16 unless noted; every launcher is asynchronous on `st`, allocates
+// nothing and is therefore hipGraph-capturable. Return 0 on success, negative on argument errors.
+#pragma once
+#include "common.h"
+
+// ---- igemm.hip
+int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st);
+
+// ---- norm.hip
+// GroupNorm statistics over the virtual channel-concat of (src0[C0], src1[C1]); stats[n][G][2] += (sum, sumsq)
+int ladi_launch_gn_stats(const h16* src0, int C0, int ld0, const h16* src1, int C1, int ld1, int n, int HW, int groups,
+                         float* stats, hipStream_t st);
+// y = act(GN(x)) (+ add): out [n][HW][C0+C1] dense
+int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int C1, int ld1, int n, int HW, int groups,
+                         const float* stats, const h16* gamma, const h16* beta, float eps, int silu, const h16* add,
+                         h16* out, hipStream_t st);
+int ladi_launch_layernorm(const h16* x, int ldx, const h16* gamma, const h16* beta, float eps, int rows, int C, h16* out,
+                          int ldo, hipStream_t st);
+// P[r][:] = softmax(scale * S[r][:]) ; S fp32 [rows][cols], P fp16
+int ladi_launch_softmax_rows(const float* S, int rows, int cols, float scale, h16* P, hipStream_t st);
+
+// ---- attention.hip
+struct AttnArgs {
+    const h16* q; const h16* k; const h16* v; h16* o;
+    int ldq, ldk, ldv, ldo;                 // row strides (elements)
+    long long sq, sk, sv, so;               // per-sample strides (elements)
+    int n, heads, Nq, Nk;                   // head h lives at column offset h*64 of each row
+    float scale;
+};
+int ladi_launch_flash_attn64(const AttnArgs& a, hipStream_t st);
+// single query per (sample, head): q [n][ldq], k/v [n][Nk][ld], generic head dim d <= 128
+int ladi_launch_attn_single_query(const h16* q, int ldq, const h16* k, int ldk, const h16* v, int ldv, h16* o, int ldo,
+                                  int n, int heads, int d, int Nk, long long sk, long long sv, float scale, hipStream_t st);
+
+// ---- elementwise.hip
+// out[m][nn] = act(sum_k x[m][k] W[nn][k] + b[nn]) for small M (weight-streaming GEMV-like); x/out fp16 or fp32
+// optional residual res[m][nn] (fp16, row stride ldr) is added after the activation
+int ladi_launch_small_linear(const void* x, int x_f32, int ldx, const h16* W, const h16* bias, const h16* res, int ldr, int M,
+                             int N, int K, int act, int pre_silu, void* out, int out_f32, int ldo, hipStream_t st);
+int ladi_launch_nchw_to_nhwc(const void* src, int src_f32, int n, int C, int H, int W, h16* dst, int ld, hipStream_t st);
+int ladi_launch_nhwc_to_nchw(const h16* src, int ld, int n, int C, int H, int W, void* dst, int dst_f32, hipStream_t st);
+// sinusoidal timestep embedding (flip_sin_to_cos=True, freq_shift=0): out[i][dim] fp32 for timesteps t[i]
+int ladi_launch_timestep_embedding(const float* t, int count, int dim, float* out, hipStream_t st);
+
+struct StepTable {            // one entry per scheduler evaluation, device resident (see sched.h)
+    float c_x;                // multiplies current sample
+    float c_e;                // multiplies the (possibly multistep-combined) epsilon
+    float w[4];               // PLMS combination weights over [eps_now, ets[-1], ets[-2], ets[-3]]
+    int   mode;               // 0 plain (use w), 1 = PLMS 2nd evaluation (eps'=(eps+ets[-1])/2, sample=cur_sample, no push)
+    int   push;               // bit0: push eps_now into the ring; bits 4-5: slot to push into;
+                              // bits 8-9 / 10-11 / 12-13: ring slots holding ets[-1] / ets[-2] / ets[-3] (before the push)
+    int   save_cur;           // 1: save current sample as cur_sample before the update
+    int   zero_cloth_next;    // 1: the NEXT evaluation must see zero cloth latents
+};
+struct StepArgs {
+    const h16* eps; int ld_eps;     // UNet output NHWC [2B or B][hw][ld_eps], channels 0..3 valid
+    int B, hw, cfg;                 // cfg: 1 = rows [0,B) uncond, [B,2B) cond
+    float guidance;
+    float* latents;                 // fp32 [B][hw][4] in/out
+    float* cur_sample;              // fp32 [B][hw][4] (PLMS)
+    float* ets;                     // fp32 [4][B][hw][4] ring (PLMS); slot = (count) & 3
+    const StepTable* table; int* step_idx;   // device step counter (read, then incremented by the kernel)
+    h16* unet_in; int ld_in;        // next UNet input [2B or B][hw][ld_in]; channels 0..3 rewritten
+    int cloth_ch0;                  // first cloth channel (27) ; zeroed when table says so (4 channels)
+};
+int ladi_launch_sched_step(const StepArgs& a, hipStream_t st);
+
+// static part of the 31-channel UNet input: mask, masked-image latents, pose, cloth; uncond half zero pose/cloth
+int ladi_launch_assemble_static(h16* unet_in, int ld_in, int B, int hw, int cfg, const float* latents, const h16* mask_lat,
+                                const float* masked_lat, const h16* pose, int pose_ch, const float* cloth_lat, int has_cloth,
+                                hipStream_t st);
+// posterior sample: lat[b][hw][4] = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scaling ; moments NHWC [..][ldm] (8 ch),
+// noise fp32 NCHW [B][4][h][w]
+int ladi_launch_posterior_sample(const h16* moments, int ldm, const float* noise_nchw, int B, int hw, float scaling, float* lat,
+                                 hipStream_t st);
+// mask binarise (>=0.5 -> 1) at full res + masked image: img NHWC (ld) *= (mask<0.5); also writes binarised mask fp16 [B][H*W]
+int ladi_launch_prepare_mask(const void* image_nchw, int img_f32, const void* mask_nchw, int mask_f32, int B, int H, int W,
+                             h16* masked_img, int ld, h16* mask_bin, hipStream_t st);
+// nearest downsample by integer factor s (top-left pixel): dst[b][h/s][w/s]
+int ladi_launch_mask_down(const h16* src, int B, int H, int W, int s, h16* dst, hipStream_t st);
+// bilinear /8 (align_corners=False == mean of centre 2x2) of pose [B][C][H][W] (NCHW) -> NHWC fp16 [B][h*w][C]
+int ladi_launch_pose_down8(const void* pose_nchw, int f32, int B, int C, int H, int W, h16* dst, hipStream_t st);
+// image = clamp(x/2+0.5, 0, 1) : src NHWC fp16 (ld) 3 valid channels -> fp32 [B][H][W][3]
+int ladi_launch_image_post(const h16* src, int ld, int n_pix, float* dst, hipStream_t st);
+// features[i] *= (1-mask) standalone (mask_features for the module-by-module shim path)
+int ladi_launch_mask_mul(h16* feat, int C, int n_pix, const h16* mask, hipStream_t st);
+int ladi_launch_fill_f32(float* p, size_t n, float v, hipStream_t st);
+// decoder input: post_quant_conv(lat / scaling_factor) -> NHWC fp16 padded to ld; pq = device [16 w | 4 b] or null (identity)
+int ladi_launch_post_quant(const float* lat, const float* pq, float inv_sf, int n, h16* dst, int ld, hipStream_t st);
+int ladi_launch_lat_nchw_to_pix(const float* src, int B, int hw, float scale, float* dst, hipStream_t st);
+int ladi_launch_lat_pix_to_nchw(const float* src, int B, int hw, float* dst, hipStream_t st);

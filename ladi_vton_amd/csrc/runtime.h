@@ -1,0 +1,219 @@
+// libladi_native runtime: weight store, device pools, activation arena, op wrappers and the module graphs
+// (extended SD2-inpainting UNet, EMASC-aware VAE, EMASC, inversion adapter, try-on pipeline).
+// Internal header; the public boundary is include/ladi_native.h.
+#pragma once
+#include "kernels.h"
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include <memory>
+
+namespace ladi {
+
+void set_error(const std::string& msg);
+const char* last_error();
+
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+struct WeightStore {
+    std::unordered_map<std::string, HostTensor> m;
+    bool has(const std::string& k) const { return m.find(k) != m.end(); }
+    const HostTensor& get(const std::string& k) const;  // throws std::runtime_error when missing
+};
+
+// persistent device memory (weights, caches): chunked bump allocator, freed with the owner
+struct DevPool {
+    std::vector<void*> chunks;
+    char* cur = nullptr;
+    size_t left = 0;
+    size_t total = 0;
+    void* alloc(size_t bytes);
+    h16* upload_h16(const std::vector<float>& v);  // fp32 host -> fp16 device
+    float* upload_f32(const std::vector<float>& v);
+    ~DevPool();
+};
+
+// transient activations: stack-discipline bump arena with a dry-run (planning) mode
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool dry = false;
+    void* alloc(size_t bytes);
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+    void reserve(size_t bytes);  // (re)allocate backing store; not capturable
+    ~Arena();
+};
+
+struct Act {  // NHWC fp16 activation view
+    h16* p = nullptr;
+    int n = 0, h = 0, w = 0, c = 0, ld = 0;
+    size_t pixels() const { return (size_t)n * h * w; }
+};
+
+struct Ctx {
+    hipStream_t st = nullptr;
+    Arena* ar = nullptr;
+    float* stats = nullptr;  // GroupNorm statistics arena (floats), zeroed at forward start
+    size_t stats_off = 0, stats_cap = 0, stats_peak = 0;
+    int err = 0;
+    bool dry() const { return ar->dry; }
+    h16* alloc_h16(size_t elems) { return reinterpret_cast<h16*>(ar->alloc(elems * sizeof(h16))); }
+    float* alloc_f32(size_t elems) { return reinterpret_cast<float*>(ar->alloc(elems * sizeof(float))); }
+    float* alloc_stats(size_t floats);
+    Act new_act(int n, int h, int w, int c, int ld = 0);
+    void check(int rc, const char* what);
+};
+
+// ------------------------------------------------------------------------------------------------
+struct DConv {  // conv3x3 / conv1x1 / linear weights in igemm layout [cout][k*k][cin_pad]
+    h16* w = nullptr; h16* b = nullptr;
+    int cin = 0, cin_pad = 0, cout = 0, k = 1;
+    int K() const { return k * k * cin_pad; }
+};
+struct DNorm { h16* g = nullptr; h16* b = nullptr; int c = 0; };
+
+struct ConvOpt {
+    int stride = 1, pad = -1 /* -1: k/2 */, ups = 0, act = LADI_ACT_NONE;
+    const float* rowadd = nullptr; const int* rowadd_idx = nullptr; int rowadd_stride = 0;
+    const Act* res0 = nullptr; const Act* res1 = nullptr;
+    const h16* mask = nullptr;
+    float out_scale = 1.f;
+    int out_ld = 0;          // 0 -> cout (GEGLU: cout/2)
+    int cfg = 0;             // igemm tile config override
+};
+
+DConv load_conv(DevPool& pool, const WeightStore& ws, const std::string& prefix, int cin_expected = -1);      // 4-D or 2-D weight
+DConv load_linear_cat(DevPool& pool, const WeightStore& ws, const std::vector<std::string>& prefixes, bool bias);  // row-concat
+DConv load_geglu(DevPool& pool, const WeightStore& ws, const std::string& prefix);
+DNorm load_norm(DevPool& pool, const WeightStore& ws, const std::string& prefix);
+
+Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& o);
+Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups, float eps, int silu, const Act* add = nullptr);
+Act layer_norm(Ctx& c, const DNorm& nm, const Act& x, float eps);
+
+// ------------------------------------------------------------------------------------------------
+struct ResBlock {
+    DNorm n1, n2; DConv c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; int temb_off = -1;
+};
+struct XfBlock {
+    DNorm gn, ln1, ln2, ln3; DConv proj_in, qkv, o1, q2, kv2, o2, ff1, ff2, proj_out; int C = 0, heads = 0;
+    h16* kv_cache = nullptr;  // [n][L][2C]
+};
+
+struct UNetCfg {
+    int in_channels = 31, out_channels = 4;
+    int boc[4] = {320, 640, 1280, 1280};
+    int heads[4] = {5, 10, 20, 20};
+    int layers_per_block = 2;
+    int cross_dim = 1024;
+    int groups = 32;
+    float eps = 1e-5f;
+};
+
+struct UNet {
+    UNetCfg cfg;
+    DevPool pool;
+    DConv conv_in, conv_out, time_l1, time_l2, temb_all;
+    DNorm norm_out;
+    std::vector<ResBlock> down_res, up_res; ResBlock mid_res[2];
+    std::vector<XfBlock> down_xf, up_xf; XfBlock mid_xf;
+    DConv down_samp[3], up_samp[3];
+    int temb_total = 0;
+    // context (cross-attention K/V) cache
+    int ctx_n = 0, ctx_L = 0, ctx_cap_n = 0;
+    DevPool ctx_pool;
+    // time-embedding table
+    float* temb_table = nullptr; int temb_rows_cap = 0; int temb_rows = 0;
+    // own arena for the stand-alone forward entry
+    Arena arena; float* stats = nullptr; size_t stats_cap = 0;
+    h16* in_buf = nullptr; size_t in_cap = 0;
+
+    void load(const UNetCfg& c, const WeightStore& ws);
+    int set_context(const h16* ehs, int n, int L, hipStream_t st);
+    int compute_temb(const float* timesteps_host, int count, hipStream_t st);  // fills temb_table rows [0,count)
+    // x: [n,h,w,64] padded NHWC input; returns eps Act [n,h,w,4(ld 4)]
+    Act forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_idx);
+    ~UNet();
+};
+
+struct VAECfg {
+    int in_channels = 3, out_channels = 3, latent_channels = 4;
+    int boc[4] = {128, 256, 512, 512};
+    int layers_per_block = 2;
+    int groups = 32;
+    float scaling_factor = 0.18215f;
+    float eps = 1e-6f;
+};
+struct VAEAttn { DNorm gn; DConv qk, v, proj; int C = 0; };
+struct VAE {
+    VAECfg cfg;
+    DevPool pool;
+    // encoder
+    DConv e_conv_in, e_conv_out /* quant_conv folded in */; DNorm e_norm_out;
+    std::vector<ResBlock> e_res; DConv e_down[3]; ResBlock e_mid[2]; VAEAttn e_attn;
+    // decoder
+    DConv d_conv_in, d_conv_out; DNorm d_norm_out; float pq_w[16]; float pq_b[4]; float* d_pq = nullptr;  // post_quant 4x4 on device
+    std::vector<ResBlock> d_res; DConv d_up[3]; ResBlock d_mid[2]; VAEAttn d_attn;
+    Arena arena; float* stats = nullptr; size_t stats_cap = 0;
+
+    void load(const VAECfg& c, const WeightStore& ws);
+    // x: [n,H,W,64] padded NHWC image. Returns moments Act [n,h,w,8]; feats[0..4] = encoder features idx1..5 (views)
+    Act encode(Ctx& c, const Act& x, Act feats[5]);
+    // z: [n,h,w,64] padded NHWC (post_quant already applied); skips[0..4] = EMASC outputs for idx1..5 or null
+    Act decode(Ctx& c, const Act& z, const Act* skips);
+    ~VAE();
+};
+
+struct EMASCCfg { int n = 5; int in_ch[8] = {128, 128, 128, 256, 512}; int out_ch[8] = {128, 256, 512, 512, 512}; };
+struct EMASC {
+    EMASCCfg cfg; DevPool pool; DConv a[8], b[8];
+    Arena arena;
+    void load(const EMASCCfg& c, const WeightStore& ws);
+    // out[i] = conv_b(silu(conv_a(feat[i]))) * (1 - mask[i])   (mask[i] may be null)
+    void forward(Ctx& c, const Act* feats, const h16* const* masks, Act* outs, bool outs_preallocated = false);
+};
+
+struct AdapterCfg { int hidden = 1280, heads = 16, mlp = 5120, head_hidden = 5120, out_dim = 16384; float ln_eps = 1e-5f; };
+struct Adapter {
+    AdapterCfg cfg; DevPool pool;
+    DNorm ln1, ln2, post_ln; DConv q, kv, o, fc1, fc2, l0, l3, l6;
+    Arena arena;
+    void load(const AdapterCfg& c, const WeightStore& ws);
+    // x [B][T][hidden] fp16 dense -> out [B][out_dim] fp16
+    int forward(const h16* x, int B, int T, h16* out, hipStream_t st);
+};
+
+struct TryOnInputs {
+    int batch, height, width, in_f32;
+    const void *image, *mask_image, *pose_map, *warped_cloth;
+    int pose_channels;
+    const h16 *prompt_embeds, *negative_prompt_embeds; int L;
+    const float *noise_cloth, *noise_latents, *noise_masked;
+    int steps; float guidance; int scheduler; float cloth_cond_rate; int no_pose; int use_graph;
+    const float* alphas_cumprod;  // optional [1000] host
+};
+struct TryOn {
+    UNet* unet = nullptr; VAE* vae = nullptr; EMASC* emasc = nullptr;
+    Arena arena; float* stats = nullptr; size_t stats_cap = 0;
+    DevPool pool;  // small persistent things
+    StepTable* d_table = nullptr; int table_cap = 0; int* d_step = nullptr;
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; unsigned long long graph_key = 0;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool ev_valid = false;
+    int last_evals = 0;
+    // stage times of the last run (ms): [0] preprocess+VAE encodes+EMASC, [1] denoising loop, [2] decode ; call after a sync
+    int stage_ms(float out[3]);
+    int run(const TryOnInputs& in, float* images_out, float* latents_out, hipStream_t st);
+    ~TryOn();
+};
+
+// scheduler tables (host): builds timesteps + StepTable entries. kind 0 = DDIM, 1 = PNDM(PLMS, skip_prk_steps)
+void default_alphas_cumprod(std::vector<float>& ac);
+void build_step_table(int kind, int steps, const float* alphas_cumprod, float cloth_cond_rate, std::vector<int>& timesteps,
+                      std::vector<StepTable>& table);
+
+}  // namespace ladi

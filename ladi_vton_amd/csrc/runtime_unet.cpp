@@ -1,0 +1,268 @@
+// Extended SD2-inpainting UNet (31 input channels) forward on the native kernels.
+// Architecture restated in SURVEY.md App. A.1-A.3 (diffusers 0.14.0 UNet2DConditionModel as configured by the
+// reference at hubconf.py:31-39 and called at src/vto_pipelines/tryon_pipe.py:732).
+#include "runtime.h"
+#include <stdexcept>
+#include <cstring>
+#include <new>
+
+namespace ladi {
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+static ResBlock load_res(DevPool& pool, const WeightStore& ws, const std::string& p, bool temb) {
+    ResBlock r;
+    r.n1 = load_norm(pool, ws, p + ".norm1");
+    r.c1 = load_conv(pool, ws, p + ".conv1");
+    r.n2 = load_norm(pool, ws, p + ".norm2");
+    r.c2 = load_conv(pool, ws, p + ".conv2");
+    r.cin = r.c1.cin; r.cout = r.c1.cout;
+    r.has_sc = ws.has(p + ".conv_shortcut.weight");
+    if (r.has_sc) r.sc = load_conv(pool, ws, p + ".conv_shortcut");
+    (void)temb;
+    return r;
+}
+
+static XfBlock load_xf(DevPool& pool, const WeightStore& ws, const std::string& p, int heads) {
+    XfBlock x;
+    x.gn = load_norm(pool, ws, p + ".norm");
+    x.proj_in = load_conv(pool, ws, p + ".proj_in");
+    const std::string b = p + ".transformer_blocks.0";
+    x.ln1 = load_norm(pool, ws, b + ".norm1");
+    x.ln2 = load_norm(pool, ws, b + ".norm2");
+    x.ln3 = load_norm(pool, ws, b + ".norm3");
+    x.qkv = load_linear_cat(pool, ws, {b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, false);
+    x.o1 = load_conv(pool, ws, b + ".attn1.to_out.0");
+    x.q2 = load_conv(pool, ws, b + ".attn2.to_q");
+    x.kv2 = load_linear_cat(pool, ws, {b + ".attn2.to_k", b + ".attn2.to_v"}, false);
+    x.o2 = load_conv(pool, ws, b + ".attn2.to_out.0");
+    x.ff1 = load_geglu(pool, ws, b + ".ff.net.0.proj");
+    x.ff2 = load_conv(pool, ws, b + ".ff.net.2");
+    x.proj_out = load_conv(pool, ws, p + ".proj_out");
+    x.C = x.proj_in.cout;
+    x.heads = heads;
+    if (x.C != heads * 64) throw std::runtime_error(p + ": head_dim must be 64");
+    return x;
+}
+
+void UNet::load(const UNetCfg& c, const WeightStore& ws) {
+    cfg = c;
+    const int L = c.layers_per_block;
+    conv_in = load_conv(pool, ws, "conv_in", c.in_channels);
+    time_l1 = load_conv(pool, ws, "time_embedding.linear_1");
+    time_l2 = load_conv(pool, ws, "time_embedding.linear_2");
+    std::vector<std::string> temb_names;
+    auto add_res = [&](std::vector<ResBlock>* vec, ResBlock* single, const std::string& p) {
+        ResBlock r = load_res(pool, ws, p, true);
+        r.temb_off = temb_total;
+        temb_total += r.cout;
+        temb_names.push_back(p + ".time_emb_proj");
+        if (vec) vec->push_back(r); else *single = r;
+    };
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < L; ++j) {
+            const std::string p = "down_blocks." + std::to_string(i);
+            add_res(&down_res, nullptr, p + ".resnets." + std::to_string(j));
+            if (i < 3) down_xf.push_back(load_xf(pool, ws, p + ".attentions." + std::to_string(j), c.heads[i]));
+        }
+        if (i < 3) down_samp[i] = load_conv(pool, ws, "down_blocks." + std::to_string(i) + ".downsamplers.0.conv");
+    }
+    add_res(nullptr, &mid_res[0], "mid_block.resnets.0");
+    mid_xf = load_xf(pool, ws, "mid_block.attentions.0", c.heads[3]);
+    add_res(nullptr, &mid_res[1], "mid_block.resnets.1");
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < L + 1; ++j) {
+            const std::string p = "up_blocks." + std::to_string(i);
+            add_res(&up_res, nullptr, p + ".resnets." + std::to_string(j));
+            if (i > 0) up_xf.push_back(load_xf(pool, ws, p + ".attentions." + std::to_string(j), c.heads[3 - i]));
+        }
+        if (i < 3) up_samp[i] = load_conv(pool, ws, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv");
+    }
+    norm_out = load_norm(pool, ws, "conv_norm_out");
+    conv_out = load_conv(pool, ws, "conv_out");
+    temb_all = load_linear_cat(pool, ws, temb_names, true);
+}
+
+UNet::~UNet() {
+    if (temb_table) (void)hipFree(temb_table);
+    if (stats) (void)hipFree(stats);
+    if (in_buf) (void)hipFree(in_buf);
+}
+
+int UNet::set_context(const h16* ehs, int n, int L, hipStream_t st) {
+    // cross-attention K/V of every transformer block depend only on encoder_hidden_states: hoisted out of the
+    // denoising loop (SURVEY.md §8d "step-invariant work")
+    std::vector<XfBlock*> all;
+    for (auto& x : down_xf) all.push_back(&x);
+    all.push_back(&mid_xf);
+    for (auto& x : up_xf) all.push_back(&x);
+    if (n * L > ctx_cap_n) {
+        ctx_pool.~DevPool();
+        new (&ctx_pool) DevPool();
+        for (auto* x : all) x->kv_cache = reinterpret_cast<h16*>(ctx_pool.alloc((size_t)n * L * 2 * x->C * sizeof(h16)));
+        ctx_cap_n = n * L;
+    }
+    ctx_n = n; ctx_L = L;
+    for (auto* x : all) {
+        IGemmArgs a; std::memset(&a, 0, sizeof(a));
+        a.src0 = ehs; a.C0 = cfg.cross_dim; a.ld0 = cfg.cross_dim;
+        a.Hs = n * L; a.Ws = 1; a.Ho = n * L; a.Wo = 1; a.P = n * L;
+        a.ksize = 1; a.stride = 1; a.pad = 0;
+        a.W = x->kv2.w; a.Q = x->kv2.cout; a.K = x->kv2.K();
+        a.out = x->kv_cache; a.ldo = 2 * x->C; a.out_scale = 1.f;
+        int rc = ladi_launch_igemm(a, 1, 0, st);
+        if (rc) { set_error("set_context igemm rc=" + std::to_string(rc)); return rc; }
+    }
+    return 0;
+}
+
+int UNet::compute_temb(const float* ts_host, int count, hipStream_t st) {
+    const int tdim = time_l1.cout;   // 1280
+    const int edim = time_l1.cin;    // 320
+    if (count > temb_rows_cap) {
+        if (temb_table) (void)hipFree(temb_table);
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&temb_table), (size_t)count * (temb_total + 2 * tdim + edim + 1) * sizeof(float)));
+        temb_rows_cap = count;
+    }
+    float* table = temb_table;                               // [count][temb_total]
+    float* t_dev = table + (size_t)temb_rows_cap * temb_total;  // [count]
+    float* emb0 = t_dev + temb_rows_cap;                     // [count][edim]
+    float* h1 = emb0 + (size_t)temb_rows_cap * edim;         // [count][tdim]
+    float* h2 = h1 + (size_t)temb_rows_cap * tdim;           // [count][tdim]
+    HIP_OK(hipMemcpyAsync(t_dev, ts_host, (size_t)count * sizeof(float), hipMemcpyHostToDevice, st));
+    int rc = ladi_launch_timestep_embedding(t_dev, count, edim, emb0, st);
+    // reference casts the sinusoid to the model dtype (fp16) before linear_1; keep fp32 (more accurate)
+    if (!rc) rc = ladi_launch_small_linear(emb0, 1, edim, time_l1.w, time_l1.b, nullptr, 0, count, tdim, time_l1.cin_pad, LADI_ACT_SILU, 0, h1, 1, tdim, st);
+    if (!rc) rc = ladi_launch_small_linear(h1, 1, tdim, time_l2.w, time_l2.b, nullptr, 0, count, tdim, time_l2.cin_pad, LADI_ACT_NONE, 0, h2, 1, tdim, st);
+    if (!rc) rc = ladi_launch_small_linear(h2, 1, tdim, temb_all.w, temb_all.b, nullptr, 0, count, temb_total, temb_all.cin_pad, LADI_ACT_NONE, 1, table, 1, temb_total, st);
+    temb_rows = count;
+    if (rc) set_error("compute_temb rc=" + std::to_string(rc));
+    return rc;
+}
+
+namespace {
+
+struct Fwd {
+    Ctx& c; UNet& u; const float* temb; const int* tidx;
+    Act res(const ResBlock& r, const Act& x, const Act* x2) {
+        Act out;
+        // block output is allocated first so temporaries can be released (stack discipline)
+        out = c.new_act(x.n, x.h, x.w, r.cout);
+        const size_t mk = c.ar->mark();
+        Act s1 = group_norm(c, r.n1, x, x2, u.cfg.groups, u.cfg.eps, 1);
+        ConvOpt o1; o1.rowadd = temb + r.temb_off; o1.rowadd_idx = tidx; o1.rowadd_stride = u.temb_total;
+        Act h1 = conv2d(c, r.c1, s1, nullptr, o1);
+        Act s2 = group_norm(c, r.n2, h1, nullptr, u.cfg.groups, u.cfg.eps, 1);
+        Act sc;
+        const Act* resid = &x;
+        if (r.has_sc) { ConvOpt os; sc = conv2d(c, r.sc, x, x2, os); resid = &sc; }
+        else if (x2) throw std::runtime_error("resnet: concat input requires conv_shortcut");
+        ConvOpt o2; o2.res0 = resid;
+        Act y = conv2d_into(r.c2, s2, o2, out);
+        c.ar->release(mk);
+        return y;
+    }
+    // conv writing into a pre-allocated output
+    Act conv2d_into(const DConv& cv, const Act& x, ConvOpt o, const Act& out) {
+        if (c.dry()) return out;
+        IGemmArgs a; std::memset(&a, 0, sizeof(a));
+        a.src0 = x.p; a.C0 = x.c; a.ld0 = x.ld;
+        a.Hs = x.h; a.Ws = x.w; a.Ho = out.h; a.Wo = out.w; a.P = out.n * out.h * out.w;
+        a.ksize = cv.k; a.stride = 1; a.pad = cv.k / 2; a.ups = 0;
+        a.W = cv.w; a.Q = cv.cout; a.K = cv.K();
+        a.bias = cv.b; a.act = o.act; a.out_scale = 1.f;
+        if (o.res0) { a.res0 = o.res0->p; a.ldr0 = o.res0->ld; }
+        if (o.res1) { a.res1 = o.res1->p; a.ldr1 = o.res1->ld; }
+        a.out = out.p; a.ldo = out.ld;
+        c.check(ladi_launch_igemm(a, 1, 0, c.st), "igemm");
+        return out;
+    }
+    Act attn(const h16* q, int ldq, long long sq, const h16* k, const h16* v, int ldkv, long long skv, int n, int T, int Nk,
+             int heads) {
+        Act o = c.new_act(n, T, 1, heads * 64);
+        if (c.dry()) return o;
+        AttnArgs a;
+        a.q = q; a.k = k; a.v = v; a.o = o.p;
+        a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = o.ld;
+        a.sq = sq; a.sk = skv; a.sv = skv; a.so = (long long)T * o.ld;
+        a.n = n; a.heads = heads; a.Nq = T; a.Nk = Nk; a.scale = 0.125f;
+        c.check(ladi_launch_flash_attn64(a, c.st), "flash_attn64");
+        return o;
+    }
+    Act xf(const XfBlock& b, const Act& x) {
+        const int n = x.n, T = x.h * x.w, C = b.C;
+        Act out = c.new_act(x.n, x.h, x.w, C);
+        const size_t mk = c.ar->mark();
+        Act g = group_norm(c, b.gn, x, nullptr, u.cfg.groups, 1e-6f, 0);
+        Act tok = g; tok.h = T; tok.w = 1;  // tokens view [n][T][C]
+        ConvOpt op;
+        Act t0 = conv2d(c, b.proj_in, tok, nullptr, op);
+        Act a1 = layer_norm(c, b.ln1, t0, 1e-5f);
+        Act qkv = conv2d(c, b.qkv, a1, nullptr, op);
+        Act o1 = attn(qkv.p, 3 * C, (long long)T * 3 * C, qkv.p + C, qkv.p + 2 * C, 3 * C, (long long)T * 3 * C, n, T, T, b.heads);
+        ConvOpt or1; or1.res0 = &t0;
+        Act t1 = conv2d(c, b.o1, o1, nullptr, or1);
+        Act a2 = layer_norm(c, b.ln2, t1, 1e-5f);
+        Act q2 = conv2d(c, b.q2, a2, nullptr, op);
+        Act o2 = attn(q2.p, C, (long long)T * C, b.kv_cache, b.kv_cache + C, 2 * C, (long long)u.ctx_L * 2 * C, n, T, u.ctx_L, b.heads);
+        ConvOpt or2; or2.res0 = &t1;
+        Act t2 = conv2d(c, b.o2, o2, nullptr, or2);
+        Act a3 = layer_norm(c, b.ln3, t2, 1e-5f);
+        ConvOpt og; og.act = LADI_ACT_GEGLU;
+        Act gg = conv2d(c, b.ff1, a3, nullptr, og);
+        ConvOpt or3; or3.res0 = &t2;
+        Act t3 = conv2d(c, b.ff2, gg, nullptr, or3);
+        Act xin = x; xin.h = T; xin.w = 1;
+        Act outv = out; outv.h = T; outv.w = 1;
+        ConvOpt oo; oo.res0 = &xin;
+        conv2d_into(b.proj_out, t3, oo, outv);
+        c.ar->release(mk);
+        return out;
+    }
+};
+
+}  // namespace
+
+Act UNet::forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_idx) {
+    if (ctx_n != x.n && !c.dry()) throw std::runtime_error("UNet::forward: set_context batch mismatch");
+    Fwd f{c, *this, temb_row, temb_idx};
+    const int L = cfg.layers_per_block;
+    std::vector<Act> skips;
+    ConvOpt o;
+    Act h = conv2d(c, conv_in, x, nullptr, o);
+    skips.push_back(h);
+    int ri = 0, xi = 0;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < L; ++j) {
+            h = f.res(down_res[ri++], h, nullptr);
+            if (i < 3) h = f.xf(down_xf[xi++], h);
+            skips.push_back(h);
+        }
+        if (i < 3) {
+            ConvOpt od; od.stride = 2; od.pad = 1;
+            h = conv2d(c, down_samp[i], h, nullptr, od);
+            skips.push_back(h);
+        }
+    }
+    h = f.res(mid_res[0], h, nullptr);
+    h = f.xf(mid_xf, h);
+    h = f.res(mid_res[1], h, nullptr);
+    ri = 0; xi = 0;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < L + 1; ++j) {
+            Act sk = skips.back(); skips.pop_back();
+            h = f.res(up_res[ri++], h, &sk);
+            if (i > 0) h = f.xf(up_xf[xi++], h);
+        }
+        if (i < 3) {
+            ConvOpt ou; ou.ups = 1;
+            h = conv2d(c, up_samp[i], h, nullptr, ou);
+        }
+    }
+    Act g = group_norm(c, norm_out, h, nullptr, cfg.groups, cfg.eps, 1);
+    ConvOpt oc; oc.out_ld = 4;
+    if (cfg.out_channels > 4) oc.out_ld = (cfg.out_channels + 3) / 4 * 4;
+    return conv2d(c, conv_out, g, nullptr, oc);
+}
+
+}  // namespace ladi

@@ -1,0 +1,104 @@
+"""Host-side mirrors of the two schedulers the reference pipeline accepts (diffusers 0.14.0 DDIMScheduler — what
+src/inference.py:123-124 instantiates — and PNDMScheduler with skip_prk_steps, which the SD2-inpainting scheduler_config.json
+describes).  They expose the attributes tryon_pipe.py touches (:74,88,331-346,650-651,711,722,740).
+
+The fused native loop (ladi_tryon_run) does not call .step(): it consumes the same tables on the device.  .step() here serves
+the module-by-module drop-in path and operates on small [B,4,h,w] tensors.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib
+
+DDIM, PNDM = 0, 1
+
+
+def _alphas_cumprod():
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+class _SchedulerBase:
+    order = 1
+    init_noise_sigma = 1.0
+    kind = None
+
+    def __init__(self):
+        self.alphas_cumprod = _alphas_cumprod()
+        self.final_alpha_cumprod = self.alphas_cumprod[0]  # set_alpha_to_one = False
+        self.config = SimpleNamespace(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                      steps_offset=1, skip_prk_steps=True, set_alpha_to_one=False, clip_sample=False,
+                                      prediction_type="epsilon")
+        self.timesteps = None
+        self.num_inference_steps = None
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def _native_timesteps(self, n):
+        import ctypes
+        buf = (ctypes.c_int * (n + 2))()
+        cnt = _lib.load().ladi_sched_timesteps(self.kind, n, buf, n + 2)
+        if cnt < 0:
+            raise _lib.NativeError("ladi_sched_timesteps: " + _lib.last_error())
+        return list(buf[:cnt])
+
+    def _a(self, t):
+        return self.alphas_cumprod[t] if t >= 0 else self.final_alpha_cumprod
+
+
+class DDIMScheduler(_SchedulerBase):
+    kind = DDIM
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        self.ratio = 1000 // num_inference_steps
+        ts = self._native_timesteps(num_inference_steps)
+        self.timesteps = torch.tensor(ts, dtype=torch.int64, device=device)
+
+    def step(self, model_output, timestep, sample, eta=0.0, generator=None, **kw):
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0 is not supported (the reference always uses eta = 0)")
+        t = int(timestep)
+        a_t, a_p = float(self._a(t)), float(self._a(t - self.ratio))
+        x, e = sample.float(), model_output.float()
+        x0 = (x - (1 - a_t) ** 0.5 * e) / a_t ** 0.5
+        prev = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * e
+        return SimpleNamespace(prev_sample=prev.to(sample.dtype))
+
+
+class PNDMScheduler(_SchedulerBase):
+    kind = PNDM
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        self.ratio = 1000 // num_inference_steps
+        ts = self._native_timesteps(num_inference_steps)
+        self.timesteps = torch.tensor(ts, dtype=torch.int64, device=device)
+        self.ets, self.counter, self.cur_sample = [], 0, None
+
+    def step(self, model_output, timestep, sample, **kw):
+        t = int(timestep)
+        tp = t - self.ratio
+        e_now, x = model_output.float(), sample.float()
+        if self.counter != 1:
+            self.ets = self.ets[-3:] + [e_now]
+        else:
+            tp, t = t, t + self.ratio
+        n = len(self.ets)
+        if n == 1 and self.counter == 0:
+            e, self.cur_sample = e_now, x
+        elif n == 1 and self.counter == 1:
+            e, x, self.cur_sample = (e_now + self.ets[-1]) / 2, self.cur_sample, None
+        elif n == 2:
+            e = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif n == 3:
+            e = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            e = (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4]) / 24
+        a_t, a_p = float(self._a(t)), float(self._a(tp))
+        denom = a_t * (1 - a_p) ** 0.5 + (a_t * (1 - a_t) * a_p) ** 0.5
+        prev = (a_p / a_t) ** 0.5 * x - (a_p - a_t) * e / denom
+        self.counter += 1
+        return SimpleNamespace(prev_sample=prev.to(sample.dtype))
