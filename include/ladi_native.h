@@ -158,6 +158,12 @@ int ladi_tryon_stage_ms(ladi_tryon* t, float* out3);
  * and return the average milliseconds per forward (synchronises). Used by bench.py for the roofline figure. */
 int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* avg_ms, void* stream);
 
+/* per-launch HIP-event timing of the implicit-GEMM kernel family (the dominant kernel): enable, run any entry point,
+ * then collect: out15[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP = 2*P*Q*K, launches}, cfg 1..4 = tile shapes
+ * (Q128xP128, Q64xP256, Q64xP64, Q128xP64), index 0 = all. collect() synchronises and clears the records. */
+void ladi_profile_igemm_enable(int on);
+int ladi_profile_igemm_collect(double* out15);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Op-level entry points (kernel parity tests; NHWC fp16 device tensors)
  * ------------------------------------------------------------------------------------------------------------- */

@@ -92,6 +92,8 @@ SIGNATURES = {
     "ladi_tryon_destroy": (None, [_P]),
     "ladi_tryon_run": (c_int, [_P, POINTER(TryOnInputs), _P, _P, _P]),
     "ladi_tryon_stage_ms": (c_int, [_P, POINTER(c_float)]),
+    "ladi_profile_igemm_enable": (None, [c_int]),
+    "ladi_profile_igemm_collect": (c_int, [POINTER(ctypes.c_double)]),
     "ladi_op_igemm": (c_int, [POINTER(IGemmDesc), c_int, c_int, _P]),
     "ladi_op_group_norm": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, _P, _P, _P]),
     "ladi_op_layer_norm": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),

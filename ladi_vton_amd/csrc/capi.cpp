@@ -357,6 +357,9 @@ int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images, fl
 }
 int ladi_tryon_stage_ms(ladi_tryon* t, float* out3) { return t ? t->t.stage_ms(out3) : -1; }
 
+void ladi_profile_igemm_enable(int on) { ladi_igemm_profile_enable(on); }
+int ladi_profile_igemm_collect(double* out15) { return ladi_igemm_profile_collect(out15); }
+
 // ------------------------------------------------------------------------------------------------ op level
 int ladi_op_igemm(const ladi_igemm_desc* d, int batch, int tile_cfg, void* stream) {
     return guarded("ladi_op_igemm", [&]() {

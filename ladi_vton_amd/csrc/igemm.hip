@@ -255,6 +255,13 @@ int launch_cfg(const IGemmArgs& a, int batch, hipStream_t st) {
 
 }  // namespace
 
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t e0, e1; int cfg; double flops; };
+bool g_prof = false;
+std::vector<ProfRec> g_recs;
+}  // namespace
+
 // Tile-shape choice. cfg: 0 = auto, 1 = Q128xP128, 2 = Q64xP256, 3 = Q64xP64, 4 = Q128xP64
 int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st) {
     if (a.ksize != 1 && a.ksize != 3) return -1;
@@ -278,11 +285,39 @@ int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st) {
         else cfg = 3;
     }
     if (geglu && cfg == 3) cfg = 4;
-    switch (cfg) {
-        case 1: return launch_cfg<2, 2, 2, 2>(a, batch, st);
-        case 2: return launch_cfg<1, 4, 2, 2>(a, batch, st);
-        case 3: return launch_cfg<2, 2, 1, 1>(a, batch, st);
-        case 4: return launch_cfg<2, 2, 2, 1>(a, batch, st);
-        default: return -7;
+    ProfRec rec;
+    const bool prof = g_prof;
+    if (prof) {
+        if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) return -12;
+        rec.cfg = cfg;
+        rec.flops = 2.0 * (double)a.P * (double)a.Q * (double)a.K * (double)batch;
+        (void)hipEventRecord(rec.e0, st);
     }
+    int rc;
+    switch (cfg) {
+        case 1: rc = launch_cfg<2, 2, 2, 2>(a, batch, st); break;
+        case 2: rc = launch_cfg<1, 4, 2, 2>(a, batch, st); break;
+        case 3: rc = launch_cfg<2, 2, 1, 1>(a, batch, st); break;
+        case 4: rc = launch_cfg<2, 2, 2, 1>(a, batch, st); break;
+        default: rc = -7;
+    }
+    if (prof) { (void)hipEventRecord(rec.e1, st); g_recs.push_back(rec); }
+    return rc;
+}
+
+// ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream around every igemm launch
+void ladi_igemm_profile_enable(int on) { g_prof = on != 0; }
+// out[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP (2*P*Q*K), launches} for cfg 1..4 (index 0 = all); clears the records
+int ladi_igemm_profile_collect(double* out15) {
+    for (int i = 0; i < 15; ++i) out15[i] = 0.0;
+    for (auto& r : g_recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return -2;
+        out15[r.cfg * 3 + 0] += ms; out15[r.cfg * 3 + 1] += r.flops; out15[r.cfg * 3 + 2] += 1.0;
+        out15[0] += ms; out15[1] += r.flops; out15[2] += 1.0;
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    g_recs.clear();
+    return 0;
 }

@@ -90,3 +90,7 @@ int ladi_launch_fill_f32(float* p, size_t n, float v, hipStream_t st);
 int ladi_launch_post_quant(const float* lat, const float* pq, float inv_sf, int n, h16* dst, int ld, hipStream_t st);
 int ladi_launch_lat_nchw_to_pix(const float* src, int B, int hw, float scale, float* dst, hipStream_t st);
 int ladi_launch_lat_pix_to_nchw(const float* src, int B, int hw, float* dst, hipStream_t st);
+
+// ---- igemm per-launch timing hooks (HIP events on the launch stream); see igemm.hip
+void ladi_igemm_profile_enable(int on);
+int ladi_igemm_profile_collect(double* out15);

@@ -205,6 +205,9 @@ struct TryOn {
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; unsigned long long graph_key = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool ev_valid = false;
     int last_evals = 0;
+    // the legacy NULL stream (torch's default) cannot be captured: work then runs on this internal stream, fenced
+    // against the caller's stream with events on entry and exit
+    hipStream_t own_stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
     // stage times of the last run (ms): [0] preprocess+VAE encodes+EMASC, [1] denoising loop, [2] decode ; call after a sync
     int stage_ms(float out[3]);
     int run(const TryOnInputs& in, float* images_out, float* latents_out, hipStream_t st);

@@ -14,6 +14,9 @@ TryOn::~TryOn() {
     if (graph) (void)hipGraphDestroy(graph);
     if (stats) (void)hipFree(stats);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
 }
 
 int TryOn::stage_ms(float out[3]) {
@@ -31,8 +34,19 @@ static unsigned long long mix(unsigned long long h, unsigned long long v) {
     return h;
 }
 
-int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hipStream_t st) {
+int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hipStream_t user_st) {
     if (!unet || !vae) { set_error("tryon: unet and vae are required"); return -1; }
+    hipStream_t st = user_st;
+    try {
+        if (!own_stream) {
+            HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+        }
+        HIP_OK(hipEventRecord(ev_in, user_st));
+        HIP_OK(hipStreamWaitEvent(own_stream, ev_in, 0));
+        st = own_stream;
+    } catch (const std::exception& e) { set_error(std::string("tryon: ") + e.what()); return -100; }
     const int B = in.batch, H = in.height, W = in.width;
     if (H % 8 || W % 8) { set_error("height and width must be divisible by 8"); return -2; }
     const int h = H / 8, w = W / 8, hw = h * w;
@@ -205,8 +219,12 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
                 }
             }
         }
+        HIP_OK(hipEventRecord(ev_out, st));
+        HIP_OK(hipStreamWaitEvent(user_st, ev_out, 0));
     } catch (const std::exception& e) {
         set_error(std::string("tryon: ") + e.what());
+        (void)hipEventRecord(ev_out, st);
+        (void)hipStreamWaitEvent(user_st, ev_out, 0);
         return -100;
     }
     return 0;

@@ -1,0 +1,242 @@
+"""Kernel-level parity (HIP through the C ABI vs plain torch fp32 on the CPU). fp16 storage / fp32 accumulation:
+tolerance rel-L2 <= 2e-3 unless stated."""
+import ctypes
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ladi_vton_amd import _lib
+from ladi_vton_amd._lib import ptr, stream_ptr
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-3
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).half().float()
+
+
+# --------------------------------------------------------------------------------------------------------------- igemm
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+def test_mfma_layout_asymmetric(cfg):
+    """transpose-detecting check of the MFMA fragment / accumulator mapping: 1x1 'conv' with an asymmetric weight."""
+    N, H, W, C, Q = 1, 16, 24, 64, 192
+    x = _rand((N, C, H, W), 1)
+    w = torch.zeros(Q, C, 1, 1)
+    for q in range(Q):
+        w[q, (q * 7) % C, 0, 0] = 1.0 + (q % 5)      # each output channel picks one (scaled) input channel
+        w[q, (q * 3 + 1) % C, 0, 0] += 0.5
+    ref = F.conv2d(x, w)
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(w), Q, ksize=1, cfg=cfg)
+    assert U.rel_l2(U.to_nchw(y), ref) < 1e-3
+
+
+@pytest.mark.parametrize("cin,cout,h,w,cfg", [(64, 64, 16, 12, 0), (128, 320, 24, 16, 0), (320, 128, 20, 12, 1), (192, 64, 32, 24, 2),
+                                              (64, 192, 9, 7, 3), (128, 128, 13, 5, 4)])
+def test_conv3x3_bias_res_temb(cin, cout, h, w, cfg):
+    N = 2
+    x, wt, b = _rand((N, cin, h, w), 2), _rand((cout, cin, 3, 3), 3, 1 / math.sqrt(9 * cin)), _rand((cout,), 4, 0.1)
+    temb, res = _rand((cout,), 5), _rand((N, cout, h, w), 6)
+    ref = F.conv2d(x, wt, b, padding=1) + temb[None, :, None, None] + res
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cout, bias=b, rowadd=temb, res0=U.nhwc16(res), cfg=cfg)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+
+
+def test_conv3x3_stride2_pad1_and_asym():
+    N, cin, cout, h, w = 2, 64, 128, 16, 12
+    x, wt, b = _rand((N, cin, h, w), 7), _rand((cout, cin, 3, 3), 8, 0.05), _rand((cout,), 9, 0.1)
+    ref = F.conv2d(x, wt, b, stride=2, padding=1)                       # UNet Downsample2D
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cout, stride=2, pad=1, bias=b)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), wt, b, stride=2, padding=0)  # VAE Downsample2D(padding=0)
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cout, stride=2, pad=0, bias=b)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+
+
+def test_conv3x3_upsample_fold():
+    N, cin, cout, h, w = 1, 128, 64, 8, 6
+    x, wt, b = _rand((N, cin, h, w), 10), _rand((cout, cin, 3, 3), 11, 0.05), _rand((cout,), 12, 0.1)
+    skip = _rand((N, cout, 2 * h, 2 * w), 13)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, b, padding=1) + skip
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cout, ups=1, bias=b, res0=U.nhwc16(skip))
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+
+
+def test_conv_concat_two_sources_and_1x1():
+    N, c0, c1, cout, h, w = 2, 128, 64, 128, 12, 8
+    a, b2 = _rand((N, c0, h, w), 14), _rand((N, c1, h, w), 15)
+    wt, b = _rand((cout, c0 + c1, 3, 3), 16, 0.03), _rand((cout,), 17, 0.1)
+    ref = F.conv2d(torch.cat([a, b2], 1), wt, b, padding=1)
+    y = U.igemm(U.nhwc16(a), U.pack_conv_weight(wt), cout, x2=U.nhwc16(b2), bias=b)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+    w1 = _rand((cout, c0 + c1, 1, 1), 18, 0.08)
+    ref = F.conv2d(torch.cat([a, b2], 1), w1, b)
+    y = U.igemm(U.nhwc16(a), U.pack_conv_weight(w1), cout, ksize=1, x2=U.nhwc16(b2), bias=b)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+
+
+def test_conv_small_cin_cout_and_mask_silu():
+    # conv_in-like (31 -> 64, zero-padded input channels) and conv_out-like (64 -> 3 with ldo 4), SiLU and (1-mask) epilogues
+    N, h, w = 1, 16, 12
+    x, wt, b = _rand((N, 31, h, w), 19), _rand((64, 31, 3, 3), 20, 0.06), _rand((64,), 21, 0.1)
+    ref = F.silu(F.conv2d(x, wt, b, padding=1))
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), 64, bias=b, act="silu")
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+    x2, w2, b2 = _rand((N, 64, h, w), 22), _rand((3, 64, 3, 3), 23, 0.05), _rand((3,), 24, 0.1)
+    mask = (torch.rand((N, 1, h, w), generator=torch.Generator().manual_seed(25)) > 0.5).float()
+    ref = F.conv2d(x2, w2, b2, padding=1) * (1 - mask)
+    y = U.igemm(U.nhwc16(x2), U.pack_conv_weight(w2), 3, bias=b2, mask=mask.reshape(-1).half().to(U.dev()), out_ld=4)
+    assert U.rel_l2(U.to_nchw(y, 3), ref) < TOL
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4])
+def test_linear_geglu(cfg):
+    T, C = 200, 128
+    x, w, b = _rand((1, C, T, 1), 26), _rand((8 * C, C), 27, 1 / math.sqrt(C)), _rand((8 * C,), 28, 0.1)
+    t = x[0, :, :, 0].t()
+    u, g = F.linear(t, w, b).chunk(2, -1)
+    ref = u * F.gelu(g)
+    half = 4 * C
+    wi, bi = torch.zeros_like(w), torch.zeros_like(b)
+    for j in range(half):
+        blk, i = divmod(j, 32)
+        wi[blk * 64 + i], wi[blk * 64 + 32 + i] = w[j], w[half + j]
+        bi[blk * 64 + i], bi[blk * 64 + 32 + i] = b[j], b[half + j]
+    y = U.igemm(U.nhwc16(x), wi.half().contiguous().to(U.dev()), 8 * C, ksize=1, bias=bi, act="geglu", cfg=cfg)
+    assert U.rel_l2(y.float().cpu().reshape(T, half), ref) < TOL
+
+
+def test_gemm_f32_out():
+    T, C = 192, 128
+    q, k = _rand((1, C, T, 1), 29), _rand((T, C), 30)
+    ref = q[0, :, :, 0].t() @ k.t()
+    y = U.igemm(U.nhwc16(q), k.half().to(U.dev()), T, ksize=1, out_f32=True)
+    assert U.rel_l2(y.cpu().reshape(T, T), ref) < 1e-3
+
+
+# --------------------------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("c0,c1,silu", [(64, 0, 1), (320, 0, 0), (128, 64, 1), (640, 320, 1)])
+def test_group_norm(lib, c0, c1, silu):
+    N, h, w, G = 2, 12, 10, 32
+    a = _rand((N, c0, h, w), 31, 2.0) + 0.5
+    b2 = _rand((N, c1, h, w), 32) if c1 else None
+    gam, bet = _rand((c0 + c1,), 33, 0.1) + 1, _rand((c0 + c1,), 34, 0.1)
+    add = _rand((N, c0 + c1, h, w), 35)
+    xcat = torch.cat([a, b2], 1) if c1 else a
+    ref = F.group_norm(xcat, G, gam, bet, 1e-5)
+    ref = (F.silu(ref) if silu else ref) + add
+    A, B2, AD = U.nhwc16(a), (U.nhwc16(b2) if c1 else None), U.nhwc16(add)
+    out = torch.empty((N, h, w, c0 + c1), dtype=torch.float16, device=U.dev())
+    stats = torch.empty((N * G * 2,), dtype=torch.float32, device=U.dev())
+    g16, b16 = gam.half().to(U.dev()), bet.half().to(U.dev())
+    rc = lib.ladi_op_group_norm(ptr(A), c0, ptr(B2), c1, N, h * w, G, ptr(g16), ptr(b16), 1e-5, silu, ptr(AD), ptr(out), ptr(stats), stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert U.rel_l2(U.to_nchw(out), ref) < TOL
+
+
+@pytest.mark.parametrize("C", [64, 320, 1280])
+def test_layer_norm(lib, C):
+    rows = 77
+    x, g, b = _rand((rows, C), 36, 3.0) + 1, _rand((C,), 37, 0.1) + 1, _rand((C,), 38, 0.1)
+    ref = F.layer_norm(x, (C,), g, b, 1e-5)
+    X, G, B = x.half().to(U.dev()), g.half().to(U.dev()), b.half().to(U.dev())
+    out = torch.empty_like(X)
+    assert lib.ladi_op_layer_norm(ptr(X), ptr(G), ptr(B), 1e-5, rows, C, ptr(out), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert U.rel_l2(out.float().cpu(), ref) < TOL
+
+
+def test_softmax_rows(lib):
+    rows, cols = 130, 192
+    s = _rand((rows, cols), 39, 4.0)
+    ref = torch.softmax(s * 0.3, -1)
+    S = s.to(U.dev())
+    P = torch.empty((rows, cols), dtype=torch.float16, device=U.dev())
+    assert lib.ladi_op_softmax_rows(ptr(S), rows, cols, 0.3, ptr(P), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert U.rel_l2(P.float().cpu(), ref) < TOL
+
+
+# --------------------------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("n,heads,Nq,Nk", [(2, 2, 192, 192), (1, 5, 300, 77), (2, 1, 48, 48), (1, 3, 768, 768), (1, 2, 33, 130)])
+def test_flash_attention(lib, n, heads, Nq, Nk):
+    C = heads * 64
+    q, k, v = _rand((n, Nq, C), 40), _rand((n, Nk, C), 41), _rand((n, Nk, C), 42)
+    qh = q.view(n, Nq, heads, 64).transpose(1, 2)
+    kh = k.view(n, Nk, heads, 64).transpose(1, 2)
+    vh = v.view(n, Nk, heads, 64).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(n, Nq, C)
+    Q, K, V = q.half().to(U.dev()), k.half().to(U.dev()), v.half().to(U.dev())
+    O = torch.empty((n, Nq, C), dtype=torch.float16, device=U.dev())
+    rc = lib.ladi_op_attention(ptr(Q), ptr(K), ptr(V), ptr(O), C, C, C, C, Nq * C, Nk * C, Nk * C, Nq * C, n, heads, Nq, Nk, 0.125, stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert U.rel_l2(O.float().cpu(), ref) < 3e-3
+
+
+def test_flash_attention_forced_rescale(lib):
+    """online-softmax rescale branch: one key row spikes late in the sequence (guide §5.4 rule 26)"""
+    n, heads, Nq, Nk, C = 1, 1, 64, 256, 64
+    q, k, v = _rand((n, Nq, C), 43), _rand((n, Nk, C), 44), _rand((n, Nk, C), 45)
+    k[0, 200] = q[0, 5] * 6.0
+    ref = torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v
+    Q, K, V = q.half().to(U.dev()), k.half().to(U.dev()), v.half().to(U.dev())
+    O = torch.empty((n, Nq, C), dtype=torch.float16, device=U.dev())
+    assert lib.ladi_op_attention(ptr(Q), ptr(K), ptr(V), ptr(O), C, C, C, C, Nq * C, Nk * C, Nk * C, Nq * C, n, heads, Nq, Nk, 0.125, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert U.rel_l2(O.float().cpu(), ref) < 3e-3
+
+
+# --------------------------------------------------------------------------------------------------------------- misc
+def test_small_linear(lib):
+    M, N, K = 19, 100, 320
+    x, w, b, r = _rand((M, K), 46), _rand((N, K), 47, 0.05), _rand((N,), 48, 0.1), _rand((M, N), 49)
+    ref = F.gelu(F.linear(F.silu(x), w, b)) + r
+    X, W, B, R = x.to(U.dev()), w.half().to(U.dev()), b.half().to(U.dev()), r.half().to(U.dev())
+    out = torch.empty((M, N), dtype=torch.float32, device=U.dev())
+    assert lib.ladi_op_small_linear(ptr(X), 1, K, ptr(W), ptr(B), ptr(R), N, M, N, K, 2, 1, ptr(out), 1, N, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert U.rel_l2(out.cpu(), ref) < TOL
+
+
+def test_layout_roundtrip(lib):
+    n, C, H, W = 2, 31, 20, 12
+    x = _rand((n, C, H, W), 50)
+    X = x.to(U.dev())
+    nh = torch.empty((n, H, W, 64), dtype=torch.float16, device=U.dev())
+    back = torch.empty((n, C, H, W), dtype=torch.float32, device=U.dev())
+    assert lib.ladi_op_nchw_to_nhwc(ptr(X), 0, n, C, H, W, ptr(nh), 64, stream_ptr()) == 0
+    assert lib.ladi_op_nhwc_to_nchw(ptr(nh), 64, n, C, H, W, ptr(back), 0, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), x)                       # exact: values are fp16-representable
+    assert float(nh[..., C:].abs().max()) == 0.0
+    assert torch.equal(nh[..., :C].float().cpu(), x.permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("kind,steps", [(0, 50), (1, 50), (0, 20), (1, 7)])
+def test_scheduler_device_vs_oracle(lib, kind, steps):
+    """fused CFG + DDIM / PLMS update on the device vs the oracle's scheduler; tolerance: fp32 rounding (rel <= 1e-5)"""
+    from oracle import pipeline as P
+    sch = P.make_scheduler(kind)
+    sch.set_timesteps(steps)
+    evals = len(sch.timesteps)
+    B, hw, gs = 2, 96, 7.5
+    g = torch.Generator().manual_seed(51)
+    eps = torch.randn((evals, 2 * B, hw, 4), generator=g).half()
+    lat0 = torch.randn((B, hw, 4), generator=g)
+    x = lat0.clone()
+    for i, t in enumerate(sch.timesteps):
+        e = eps[i].float()
+        eu, ec = e[:B], e[B:]
+        x = sch.step(eu + gs * (ec - eu), t, x)
+    E, L = eps.to(U.dev()), lat0.clone().to(U.dev())
+    ac = P.alphas_cumprod().contiguous()
+    rc = lib.ladi_op_sched_run(kind, steps, ctypes.c_void_p(ac.data_ptr()), ptr(E), evals, B, hw, 1, gs, ptr(L), stream_ptr())
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    assert U.rel_l2(L.cpu(), x) < 1e-5

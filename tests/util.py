@@ -1,0 +1,90 @@
+"""Shared helpers for the parity tests (HIP path called through the C ABI vs the CPU oracle / plain torch fp32)."""
+import ctypes
+import math
+
+import torch
+
+from ladi_vton_amd import _lib
+from ladi_vton_amd._lib import IGemmDesc, ptr, stream_ptr
+
+ACT = dict(none=0, silu=1, gelu=2, geglu=3)
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def nhwc16(x):
+    """[N,C,H,W] fp32 cpu -> NHWC fp16 on the GPU, channels zero-padded to a multiple of 64"""
+    n, c, h, w = x.shape
+    cp = (c + 63) // 64 * 64
+    out = torch.zeros((n, h, w, cp), dtype=torch.float16)
+    out[..., :c] = x.permute(0, 2, 3, 1).half()
+    return out.to(dev())
+
+
+def pack_conv_weight(w):
+    """[cout,cin,k,k] -> [cout, k*k, cin_pad] fp16 (tap-major, channel-minor; the igemm layout)"""
+    co, ci, k, _ = w.shape
+    cp = (ci + 63) // 64 * 64
+    out = torch.zeros((co, k * k, cp), dtype=torch.float16)
+    out[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, k * k, ci).half()
+    return out.reshape(co, k * k * cp).contiguous().to(dev())
+
+
+def pack_conv_weight_cat(w, c0, c1):
+    """conv weight over a channel concat (c0 | c1), each padded separately? no: both are multiples of 64 in the model."""
+    return pack_conv_weight(w)
+
+
+def igemm(x, w_packed, cout, ksize=3, stride=1, pad=None, ups=0, x2=None, bias=None, rowadd=None, act="none", res0=None, res1=None,
+          mask=None, out_f32=False, cfg=0, out_ld=None):
+    """x, x2: NHWC fp16 gpu tensors [N,H,W,C]; returns NHWC output [N,Ho,Wo,ldo]"""
+    lib = _lib.load()
+    N, H, W, C0 = x.shape
+    C1 = x2.shape[3] if x2 is not None else 0
+    Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = (Hl, Wl) if stride == 1 else (Hl // 2, Wl // 2)
+    qout = cout // 2 if act == "geglu" else cout
+    ldo = out_ld or qout
+    out = torch.zeros((N, Ho, Wo, ldo), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
+    d = IGemmDesc()
+    d.src0, d.C0, d.ld0 = x.data_ptr(), C0, C0
+    if x2 is not None:
+        d.src1, d.C1, d.ld1 = x2.data_ptr(), C1, C1
+    d.Hs, d.Ws, d.Ho, d.Wo, d.P = H, W, Ho, Wo, N * Ho * Wo
+    d.ksize, d.stride, d.pad, d.ups = ksize, stride, (ksize // 2 if pad is None else pad), ups
+    d.W, d.Q, d.K, d.ldw = w_packed.data_ptr(), cout, ksize * ksize * (C0 + C1), 0
+    keep = []
+    if bias is not None:
+        b = bias.half().to(x.device); keep.append(b); d.bias = b.data_ptr()
+    if rowadd is not None:
+        r = rowadd.float().to(x.device); keep.append(r); d.rowadd = r.data_ptr()
+    d.act, d.out_scale = ACT[act], 1.0
+    if res0 is not None:
+        d.res0, d.ldr0 = res0.data_ptr(), res0.shape[3]
+    if res1 is not None:
+        d.res1, d.ldr1 = res1.data_ptr(), res1.shape[3]
+    if mask is not None:
+        d.mask = mask.data_ptr()
+    d.out, d.ldo, d.out_f32 = out.data_ptr(), ldo, int(out_f32)
+    rc = lib.ladi_op_igemm(ctypes.byref(d), 1, cfg, stream_ptr())
+    assert rc == 0, "igemm rc=%d %s" % (rc, _lib.last_error())
+    torch.cuda.synchronize()
+    return out
+
+
+def to_nchw(y, c=None):
+    y = y.float().cpu().permute(0, 3, 1, 2)
+    return y[:, :c] if c is not None else y
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def psnr(a, b, peak=None):
+    a, b = a.double(), b.double()
+    peak = float(b.abs().max()) if peak is None else peak
+    mse = float(((a - b) ** 2).mean())
+    return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)
