@@ -1,0 +1,234 @@
+"""CPU-only tests: the oracle against the golden vectors / known-answer anchors, host logic of the product (schedulers,
+input validation, sharding) and the C-ABI surface (library loads, exports every declared symbol; no compute without a GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import configs as C
+from oracle import models as M
+from oracle import pipeline as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# --------------------------------------------------------------------------------------------------------------- oracle pins
+def test_parameter_counts_match_known_sizes():
+    """the restated module trees must reproduce the well-known sizes to the unit"""
+    assert C.param_count(C.unet_shapes(C.UNET_FULL)) == 865_988_484
+    assert C.param_count(C.unet_shapes(dict(C.UNET_FULL, in_channels=4))) == 865_910_724
+    assert C.param_count(C.unet_shapes(dict(C.UNET_FULL, in_channels=9))) == 865_925_124
+    assert C.param_count(C.vae_shapes(C.VAE_FULL)) == 83_653_863
+    assert C.param_count(C.emasc_shapes(C.EMASC_FULL)) == 7_965_696
+    assert C.param_count(C.adapter_shapes(C.ADAPTER_FULL)) == 136_360_704
+    assert C.emasc_for_vae(C.VAE_FULL) == C.EMASC_FULL
+
+
+def test_scheduler_known_answers():
+    """SURVEY.md App. A.5 anchors"""
+    ac = P.alphas_cumprod()
+    for t, v in {0: 0.99914998, 1: 0.99829602, 21: 0.98038065, 961: 0.00728172, 981: 0.00577550, 999: 0.00466010}.items():
+        assert abs(float(ac[t]) - v) < 2e-7 * max(1.0, v / 1e-3)
+    d = P.DDIM(); d.set_timesteps(50)
+    assert d.timesteps[:3] == [981, 961, 941] and d.timesteps[-2:] == [21, 1] and len(d.timesteps) == 50
+    d.set_timesteps(20); assert d.timesteps[:3] == [951, 901, 851]
+    d.set_timesteps(100); assert d.timesteps[:3] == [991, 981, 971]
+    p = P.PNDM(); p.set_timesteps(50)
+    assert p.timesteps[:4] == [981, 961, 961, 941] and p.timesteps[-1] == 1 and len(p.timesteps) == 51
+    # product of the DDIM x-coefficients over 50 steps (how much the sampler alone amplifies a latent perturbation)
+    d.set_timesteps(50)
+    prod = 1.0
+    for t in d.timesteps:
+        tp = t - 20
+        prod *= (float(ac[tp] if tp >= 0 else ac[0]) / float(ac[t])) ** 0.5
+    assert abs(prod - 13.15) < 0.02
+
+
+def test_oracle_matches_reference_emasc_fixture():
+    """fixtures were produced by the REAL reference modules (oracle/make_golden.py): src/models/emasc.py, src/utils/data_utils.py"""
+    g = load_file(os.path.join(GOLD, "emasc_tiny.safetensors"))
+    sd = C.synth_state_dict(C.emasc_shapes(C.EMASC_TINY), "emasc.")
+    outs = M.emasc_forward(sd, [g["feat%d" % i] for i in range(5)])
+    for i in range(5):
+        assert torch.allclose(outs[i], g["emasc%d" % i], atol=1e-5, rtol=1e-5)
+    mk = M.mask_features(outs, g["mask"])
+    for i in range(5):
+        assert torch.allclose(mk[i], g["masked%d" % i], atol=1e-5, rtol=1e-5)
+
+
+def test_oracle_matches_transformers_clip_layer_fixture():
+    c = load_file(os.path.join(GOLD, "clip_encoder_layer_tiny.safetensors"))
+    sd = C.synth_state_dict(C.adapter_shapes(C.ADAPTER_TINY), "adapter.")
+    y = M.clip_encoder_layer(sd, "encoder_layers.0", c["x"], C.ADAPTER_TINY["heads"], C.ADAPTER_TINY["layer_norm_eps"])
+    assert torch.allclose(y, c["y"], atol=2e-5, rtol=1e-5)
+
+
+def test_mask_features_progressive_equals_strided():
+    """the progressive nearest chain equals mask[..., ::s, ::s] (what the native kernels implement)"""
+    g = torch.Generator().manual_seed(0)
+    mask = (torch.rand((2, 1, 64, 48), generator=g) > 0.5).float()
+    feats = [torch.ones(2, 1, 64, 48), torch.ones(2, 1, 64, 48), torch.ones(2, 1, 32, 24), torch.ones(2, 1, 16, 12), torch.ones(2, 1, 8, 6)]
+    out = M.mask_features(feats, mask)
+    for f, s in zip(out, (1, 1, 2, 4, 8)):
+        assert torch.equal(f, 1 - mask[..., ::s, ::s])
+    pose = torch.rand((1, 3, 64, 48), generator=g)
+    lo = torch.nn.functional.interpolate(pose, size=(8, 6), mode="bilinear")
+    ref = 0.25 * (pose[..., 3::8, 3::8] + pose[..., 3::8, 4::8] + pose[..., 4::8, 3::8] + pose[..., 4::8, 4::8])
+    assert torch.allclose(lo, ref, atol=1e-6)
+
+
+def test_oracle_pipeline_smoke_and_cloth_quirk():
+    """tiny oracle pipeline runs; PNDM zeroes the cloth latents at the LAST evaluation only (tryon_pipe.py:718-719)"""
+    usd = C.synth_state_dict(C.unet_shapes(C.UNET_TINY), "unet.")
+    vsd = C.synth_state_dict(C.vae_shapes(C.VAE_TINY), "vae.")
+    esd = C.synth_state_dict(C.emasc_shapes(C.EMASC_TINY), "emasc.")
+    inp = P.synthetic_inputs(1, 64, 64, L=4, D=C.UNET_TINY["cross_attention_dim"])
+    seen = []
+
+    def spy(x, t, e):
+        seen.append(float(x[:, 27:31].abs().max()))
+        return torch.zeros(x.shape[0], 4, x.shape[2], x.shape[3])
+
+    img, lat = P.tryon_pipeline(usd, C.UNET_TINY, vsd, C.VAE_TINY, esd, inp, num_inference_steps=4, scheduler="pndm", unet_fn=spy)
+    assert img.shape == (1, 64, 64, 3) and float(img.min()) >= 0 and float(img.max()) <= 1
+    assert len(seen) == 5 and all(v > 0 for v in seen[:4]) and seen[4] == 0.0
+
+
+# --------------------------------------------------------------------------------------------------------------- C ABI surface
+def test_library_loads_and_exports_every_declared_symbol(lib):
+    from ladi_vton_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "ladi_native.h")).read()
+    declared = set(re.findall(r"\b(ladi_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (ladi_[a-z0-9_]+)", nm))
+    assert declared <= exported, declared - exported
+    assert lib.ladi_version() >= 100
+
+
+def test_native_host_scheduler_tables_match_oracle(lib):
+    buf = (ctypes.c_int * 1100)()
+    for kind in (0, 1):
+        for n in (7, 20, 50, 100):
+            cnt = lib.ladi_sched_timesteps(kind, n, buf, 1100)
+            sch = P.make_scheduler(kind); sch.set_timesteps(n)
+            assert list(buf[:cnt]) == sch.timesteps
+    out = (ctypes.c_float * 1000)()
+    assert lib.ladi_sched_alphas_cumprod(out) == 0
+    ac = P.alphas_cumprod()
+    got = torch.tensor(list(out))
+    assert float(((got - ac).abs() / ac).max()) < 5e-6
+
+
+def test_no_cpu_fallback():
+    import ladi_vton_amd as L
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(L.NativeError):
+        L.NativeUNet(C.UNET_TINY, {})
+    with pytest.raises(L.NativeError):
+        L.build_random_init_pipeline("tiny")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ladi_vton_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "/root/reference" not in src, f
+
+
+# --------------------------------------------------------------------------------------------------------------- host logic
+def test_shim_schedulers_match_oracle_on_cpu():
+    import ladi_vton_amd as L
+    g = torch.Generator().manual_seed(3)
+    for kind, cls in ((0, L.DDIMScheduler), (1, L.PNDMScheduler)):
+        s, o = cls(), P.make_scheduler(kind)
+        s.set_timesteps(9); o.set_timesteps(9)
+        assert [int(t) for t in s.timesteps] == o.timesteps
+        x = torch.randn((2, 4, 8, 6), generator=g)
+        xs, xo = x.clone(), x.clone()
+        for t in o.timesteps:
+            e = torch.randn((2, 4, 8, 6), generator=g)
+            xs = s.step(e, t, xs).prev_sample
+            xo = o.step(e, t, xo)
+        assert torch.allclose(xs, xo, rtol=1e-5, atol=1e-5)
+        assert s.init_noise_sigma == 1.0 and s.order == 1 and s.config.steps_offset == 1 and s.config.skip_prk_steps is True
+        assert s.scale_model_input(x, 5) is x
+
+
+def test_pipeline_check_inputs_errors():
+    """same ValueErrors as tryon_pipe.py:362-407"""
+    import ladi_vton_amd as L
+    from types import SimpleNamespace
+    vae = SimpleNamespace(config=SimpleNamespace(block_out_channels=(1, 2, 3, 4)))
+    pipe = L.StableDiffusionTryOnePipeline(vae=vae, text_encoder=None, tokenizer=None, unet=SimpleNamespace(), scheduler=L.DDIMScheduler())
+    assert pipe.vae_scale_factor == 8
+    pe = torch.zeros(1, 77, 8)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, 510, 384, 1, prompt_embeds=pe)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, 512, 384, 0, prompt_embeds=pe)
+    with pytest.raises(ValueError):
+        pipe.check_inputs("a", 512, 384, 1, prompt_embeds=pe)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, 512, 384, 1)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, 512, 384, 1, prompt_embeds=pe, negative_prompt_embeds=torch.zeros(2, 77, 8))
+    pipe.check_inputs(None, 512, 384, 1, prompt_embeds=pe, negative_prompt_embeds=pe)
+    with pytest.raises(ValueError):
+        L.StableDiffusionTryOnePipeline._validate_images(torch.full((1, 3, 8, 8), 2.0), torch.zeros(1, 1, 8, 8))
+    with pytest.raises(ValueError):
+        L.StableDiffusionTryOnePipeline._validate_images(torch.zeros(1, 3, 8, 8), torch.zeros(1, 1, 4, 8))
+
+
+def test_shard_bounds_cover_batch():
+    from ladi_vton_amd.parallel import shard_bounds
+    for B in (1, 7, 8, 32, 255, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from ladi_vton_amd.parallel import run_sharded, shard_bounds
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+B = 5   # ragged over 2 ranks
+g = torch.Generator().manual_seed(7)
+inputs = dict(image=torch.rand((B, 3, 8, 6), generator=g), noise=torch.rand((B, 4, 1, 1), generator=g), scalar=3)
+def run_local(loc):   # stand-in for the per-rank pipeline: a per-sample function of the sharded inputs
+    assert loc["scalar"] == 3
+    return (loc["image"] * loc["noise"][:, :3]).permute(0, 2, 3, 1).contiguous()
+out = run_sharded(run_local, inputs)
+ref = ((inputs["image"] * inputs["noise"][:, :3]).permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8)
+assert out.shape == ref.shape and torch.equal(out, ref), (rank, out.shape)
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_sharded_run_world_size_2_gloo(tmp_path):
+    """N > 1 path on CPU: batch sharding + the all-gather of uint8 images, world_size 2, gloo, ragged batch"""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    port = str(29500 + (os.getpid() % 500))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("OK %d" % r) in o, o
