@@ -159,10 +159,13 @@ int ladi_tryon_stage_ms(ladi_tryon* t, float* out3);
 int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* avg_ms, void* stream);
 
 /* per-launch HIP-event timing of the implicit-GEMM kernel family (the dominant kernel): enable, run any entry point,
- * then collect: out15[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP = 2*P*Q*K, launches}, cfg 1..4 = tile shapes
- * (Q128xP128, Q64xP256, Q64xP64, Q128xP64), index 0 = all. collect() synchronises and clears the records. */
+ * then collect: out[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP = 2*P*Q*K, launches}, cfg 1..6 = tile shapes
+ * (Q128xP256, Q320xP128, Q128xP128, Q128xP64, Q64xP64, Q256xP128), index 0 = all; n_out >= 21. collect() synchronises and clears the records. */
+/* measured tile-shape selection (default on): the first launch of a new problem shape outside a stream capture times the
+ * admissible tile configurations and caches the fastest; off = static cost model */
+void ladi_igemm_set_autotune(int on);
 void ladi_profile_igemm_enable(int on);
-int ladi_profile_igemm_collect(double* out15);
+int ladi_profile_igemm_collect(double* out, int n_out);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Op-level entry points (kernel parity tests; NHWC fp16 device tensors)
@@ -172,7 +175,7 @@ typedef struct {
     const void* W; int Q, K, ldw; long long bs_src0, bs_w, bs_out, bs_res;
     const void* bias; int bias_per_pixel; const float* rowadd; const int* rowadd_idx; int rowadd_stride; int act; float out_scale;
     const void* res0; const void* res1; int ldr0, ldr1; const void* mask; void* out; int ldo; int out_f32;
-    float* stats; int stats_groups;
+    float* stats; int stats_groups; int tile_map /* ignored: set by the launcher */;
 } ladi_igemm_desc;
 int ladi_op_igemm(const ladi_igemm_desc* d, int batch, int tile_cfg, void* stream);
 int ladi_op_group_norm(const void* src0, int C0, const void* src1, int C1, int n, int HW, int groups, const void* gamma,

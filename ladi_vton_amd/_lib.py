@@ -57,7 +57,7 @@ class IGemmDesc(Structure):
                 ("bias", c_void_p), ("bias_per_pixel", c_int), ("rowadd", c_void_p), ("rowadd_idx", c_void_p),
                 ("rowadd_stride", c_int), ("act", c_int), ("out_scale", c_float),
                 ("res0", c_void_p), ("res1", c_void_p), ("ldr0", c_int), ("ldr1", c_int), ("mask", c_void_p),
-                ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("stats", c_void_p), ("stats_groups", c_int)]
+                ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("stats", c_void_p), ("stats_groups", c_int), ("tile_map", c_int)]
 
 
 # every symbol include/ladi_native.h declares: name -> (restype, argtypes)
@@ -92,8 +92,9 @@ SIGNATURES = {
     "ladi_tryon_destroy": (None, [_P]),
     "ladi_tryon_run": (c_int, [_P, POINTER(TryOnInputs), _P, _P, _P]),
     "ladi_tryon_stage_ms": (c_int, [_P, POINTER(c_float)]),
+    "ladi_igemm_set_autotune": (None, [c_int]),
     "ladi_profile_igemm_enable": (None, [c_int]),
-    "ladi_profile_igemm_collect": (c_int, [POINTER(ctypes.c_double)]),
+    "ladi_profile_igemm_collect": (c_int, [POINTER(ctypes.c_double), c_int]),
     "ladi_op_igemm": (c_int, [POINTER(IGemmDesc), c_int, c_int, _P]),
     "ladi_op_group_norm": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, _P, _P, _P]),
     "ladi_op_layer_norm": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),

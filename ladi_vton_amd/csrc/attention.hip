@@ -18,7 +18,7 @@ constexpr int VT_LD = 68;  // halves per V^T row (136 B: conflict-free 8-byte co
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-__global__ __launch_bounds__(256) void flash_attn64_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) h16 sK[KV_TILE * 64];
     __shared__ __attribute__((aligned(16))) h16 sVt[64 * VT_LD];
 

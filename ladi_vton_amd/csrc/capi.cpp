@@ -135,7 +135,7 @@ int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* 
             if (!c.dry()) HIP_OK(hipEventRecord(e0, st));
             for (int i = 0; i < (c.dry() ? 1 : iters); ++i) {
                 c.stats_off = 0;
-                if (!c.dry()) HIP_OK(hipMemsetAsync(c.stats, 0, c.stats_cap * sizeof(float), st));
+                if (!c.dry() && c.stats_cap) HIP_OK(hipMemsetAsync(c.stats, 0, c.stats_cap * sizeof(float), st));
                 (void)U.forward(c, x, U.temb_table, nullptr);
                 c.ar->release(mk);
             }
@@ -357,8 +357,9 @@ int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images, fl
 }
 int ladi_tryon_stage_ms(ladi_tryon* t, float* out3) { return t ? t->t.stage_ms(out3) : -1; }
 
+void ladi_igemm_set_autotune(int on) { ladi_igemm_autotune(on); }
 void ladi_profile_igemm_enable(int on) { ladi_igemm_profile_enable(on); }
-int ladi_profile_igemm_collect(double* out15) { return ladi_igemm_profile_collect(out15); }
+int ladi_profile_igemm_collect(double* out, int n_out) { return ladi_igemm_profile_collect(out, n_out); }
 
 // ------------------------------------------------------------------------------------------------ op level
 int ladi_op_igemm(const ladi_igemm_desc* d, int batch, int tile_cfg, void* stream) {
@@ -374,10 +375,18 @@ int ladi_op_group_norm(const void* src0, int C0, const void* src1, int C1, int n
                        float eps, int silu, const void* add, void* out, float* stats, void* stream) {
     return guarded("ladi_op_group_norm", [&]() {
         hipStream_t st = S(stream);
-        HIP_OK(hipMemsetAsync(stats, 0, (size_t)n * groups * 2 * sizeof(float), st));
-        int rc = ladi_launch_gn_stats((const h16*)src0, C0, C0, (const h16*)src1, C1, C1, n, HW, groups, stats, st);
-        if (!rc) rc = ladi_launch_gn_apply((const h16*)src0, C0, C0, (const h16*)src1, C1, C1, n, HW, groups, stats, (const h16*)gamma,
-                                           (const h16*)beta, eps, silu, (const h16*)add, (h16*)out, st);
+        (void)stats;  // legacy scratch argument (unused: statistics are atomics-free partial rows now)
+        const int r0 = ladi_gn_partial_rows(n, HW, C0), r1 = C1 ? ladi_gn_partial_rows(n, HW, C1) : 0;
+        const size_t f0 = (size_t)n * r0 * C0 * 2, f1 = (size_t)n * r1 * C1 * 2, fs = (size_t)n * (C0 + C1) * 2;
+        float* buf = nullptr;
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&buf), (f0 + f1 + fs) * sizeof(float)));
+        int rc = ladi_launch_gn_partial((const h16*)src0, C0, C0, n, HW, buf, st);
+        if (!rc && C1) rc = ladi_launch_gn_partial((const h16*)src1, C1, C1, n, HW, buf + f0, st);
+        if (!rc) rc = ladi_launch_gn_finalize(buf, C0, r0, buf + f0, C1, r1, n, HW, groups, (const h16*)gamma, (const h16*)beta, eps, buf + f0 + f1, st);
+        if (!rc) rc = ladi_launch_gn_apply((const h16*)src0, C0, C0, (const h16*)src1, C1, C1, n, HW, buf + f0 + f1, silu, (const h16*)add,
+                                           (h16*)out, st);
+        HIP_OK(hipStreamSynchronize(st));
+        (void)hipFree(buf);
         return rc;
     });
 }

@@ -71,6 +71,7 @@ struct IGemmArgs {
     const h16* mask;     // [P] fp16; out *= (1 - mask[p]) or null
     void* out; int ldo;  // [P][ldo]
     int out_f32;         // 1: store fp32
-    float* stats;        // optional GroupNorm partial sums of the OUTPUT: [n][groups][2] (sum, sumsq), atomics
-    int stats_groups;    // number of groups (channels per group = Qout / groups)
+    float* stats;        // optional per-channel partial statistics of the OUTPUT: rows of [Q][2] (sum, sumsq), see kernels.h
+    int stats_groups;    // unused
+    int tile_map;        // set by the launcher: 0 plain, 1 pixel tiles split over XCDs, 2 channel tiles split over XCDs
 };

@@ -5,114 +5,151 @@
 //   conv1x1, nn.Linear, and the batched products of the VAE mid-block attention.
 //
 // Orientation: D[q][p] = sum_k W[q][k] * X[p][k]   (q = output channel, p = output pixel / token)
-//   A operand (MFMA rows)  = weight tile  [BQ][64]  staged in LDS
-//   B operand (MFMA cols)  = gathered activation tile [BP][64] staged in LDS (im2col done by the gather)
+//   A operand (MFMA rows)  = weight tile  [BQ][BK]  in LDS
+//   B operand (MFMA cols)  = gathered activation tile [BP][BK] in LDS (im2col is done by the per-lane gather address)
 //   -> every lane ends up owning ONE pixel (col = lane&31) and groups of 4 CONSECUTIVE output channels
 //      (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), so NHWC epilogue loads/stores are 8-byte vectors and
 //      per-pixel quantities (mask) are lane-local.
 //
-// Tiles: block = 256 threads = 4 waves (WQ x WP), each wave owns (TQ*32) x (TP*32) outputs.
-// K loop: BK = 64 halves (128-byte rows) per step, register-staged global->LDS double buffering
-// (one barrier per step).  LDS rows are XOR-swizzled in 16-byte chunks with ((row>>1)&7) so that both the
-// 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups are bank-conflict free
-// (MI355X_MICROARCH.md §LDS: ds_read_b128 bank = (addr/4)%64, 4x16-lane groups).
+// Data movement (the part that bounds this kernel: LDS write bandwidth is ~1/3 of LDS read bandwidth on CDNA4):
+//   * global -> LDS goes through the LDS-DMA path (`buffer_load_dwordx4 ... offen lds`): no VGPR round trip and no
+//     ds_write instructions.  Zero padding of the convolution halo, ragged tile rows and rows >= Q come for free from
+//     the buffer descriptor's bounds check (an out-of-range voffset returns 0 into LDS).
+//   * the LDS image of a DMA is lane-linear (M0 base + lane*16 B), so the bank-conflict XOR swizzle is applied to the
+//     per-lane SOURCE address and again on the ds_read_b128 side (cdna_hip_programming.md §5.4 rule 21).
+//   * NST-stage LDS ring, one raw s_barrier per K step, counted vmcnt so that up to NST-1 stages stay in flight.
+//   * workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): each XCD walks a contiguous range of pixel
+//     (or channel) tiles so co-resident workgroups share operand panels in that XCD's private L2.
 #include "common.h"
 #include "kernels.h"
+#include <vector>
+#include <unordered_map>
+#include <map>
+#include <string>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
-constexpr int BK = 64;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__device__ __forceinline__ int swz(int row, int chunk) { return (row * BK) + (((chunk ^ ((row >> 1) & 7))) << 3); }
+template <int V> struct IntC { static constexpr int value = V; };
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IntC<I>{}); static_for<I + 1, N>(f); }
+}
 
-template <int WQ, int WP, int TQ, int TP>
-__global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
+template <int BK>
+__device__ __forceinline__ int swz(int row, int chunk) {
+    if constexpr (BK == 64) return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
+    else return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3);
+}
+
+template <int WQ, int WP, int TQ, int TP, int BK, int NST>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmArgs a) {
     constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
-    constexpr int RQ = BQ / 32, RP = BP / 32;
+    constexpr int CPR = BK / 8;          // 16-byte chunks per LDS row
+    constexpr int RPP = 256 / CPR;       // tile rows covered by one pass of the 256 threads
+    constexpr int RQ = BQ / RPP, RP = BP / RPP;
+    constexpr int STAGE = (BQ + BP) * BK;  // halves per stage
+    constexpr int NKK = BK / 16;
+    static_assert(NST == 2 || NST == 3, "ring depth");
+    static_assert(BQ % RPP == 0 && BP % RPP == 0, "tile rows must be a multiple of the rows per pass");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     h16* smem = reinterpret_cast<h16*>(smem_raw);
-    // layout: buf0: [W tile BQ*64][X tile BP*64]  buf1: same
-    constexpr int BUF = (BQ + BP) * BK;
 
     const int tid = threadIdx.x;
-    const int nq = (a.Q + BQ - 1) / BQ;
-    const int tile = blockIdx.x;
-    const int q0 = (tile % nq) * BQ;
-    const int p0 = (tile / nq) * BP;
+    const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
+    int qt, pt;
+    {
+        const int b = blockIdx.x;
+        if (a.tile_map == 1) {          // pixel tiles split across the 8 XCDs, q fastest inside an XCD
+            const int npx = (np + 7) >> 3, xcd = b & 7, loc = b >> 3;
+            pt = xcd * npx + loc / nq; qt = loc % nq;
+            if (pt >= np) return;
+        } else if (a.tile_map == 2) {   // channel tiles split across the XCDs, p fastest inside an XCD
+            const int nqx = (nq + 7) >> 3, xcd = b & 7, loc = b >> 3;
+            qt = xcd * nqx + loc / np; pt = loc % np;
+            if (qt >= nq) return;
+        } else { qt = b % nq; pt = b / nq; }
+    }
+    const int q0 = qt * BQ, p0 = pt * BP;
     const int z = blockIdx.z;
 
-    const h16* __restrict__ src0 = a.src0 + (size_t)z * a.bs_src0;
-    const h16* __restrict__ src1 = a.src1;
-    const h16* __restrict__ Wp = a.W + (size_t)z * a.bs_w;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int cphys = tid % CPR;          // physical chunk this lane's DMA lands in
+    const int r0 = tid / CPR;             // row within a pass
+    const int clog = (BK == 64) ? (cphys ^ ((r0 >> 1) & 7)) : (cphys ^ ((r0 >> 2) & 3));  // logical chunk it must fetch
 
-    const int c8 = tid & 7;
-    const int r0 = tid >> 3;  // 0..31
-    const int swz_chunk = ((c8 ^ ((r0 >> 1) & 7)) << 3);  // (r0 + 32*i)>>1 & 7 == (r0>>1)&7
+    // ---- buffer descriptors (wave-uniform); activation descriptors are rebased to the tile's first sample so that
+    //      32-bit byte offsets never overflow
+    const int HoWo = a.Ho * a.Wo;
+    const int HsWs = a.Hs * a.Ws;
+    const int n_first = p0 / HoWo;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.src0 + (size_t)z * a.bs_src0 + (size_t)n_first * HsWs * a.ld0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.src1 ? a.src1 + (size_t)n_first * HsWs * a.ld1 : a.src0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.W + (size_t)z * a.bs_w), 0, 0x7FFFFFFF, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
 
     // ---- per-thread pixel-row decode (constant over the K loop)
-    const int HoWo = a.Ho * a.Wo;
     const int Hlog = a.ups ? 2 * a.Hs : a.Hs;
     const int Wlog = a.ups ? 2 * a.Ws : a.Ws;
     int nb[RP], iy0[RP], ix0[RP];
 #pragma unroll
     for (int i = 0; i < RP; ++i) {
-        int p = p0 + r0 + 32 * i;
-        bool ok = p < a.P;
-        int pp = ok ? p : 0;
-        int n = pp / HoWo;
-        int rem = pp - n * HoWo;
-        int oy = rem / a.Wo;
-        int ox = rem - oy * a.Wo;
+        const int p = p0 + r0 + RPP * i;
+        const bool ok = p < a.P;
+        const int pp = ok ? p : 0;
+        const int n = pp / HoWo;
+        const int rem = pp - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
         iy0[i] = ok ? (oy * a.stride - a.pad) : -100000;  // invalid rows fail the bounds test
         ix0[i] = ox * a.stride - a.pad;
-        nb[i] = n * a.Hs * a.Ws;
+        nb[i] = (n - n_first) * HsWs;
+    }
+    const int ldw = a.ldw ? a.ldw : a.K;
+    unsigned wbase[RQ];
+#pragma unroll
+    for (int i = 0; i < RQ; ++i) {
+        const int q = q0 + r0 + RPP * i;
+        wbase[i] = (q < a.Q) ? (unsigned)(((size_t)q * ldw + clog * 8) * 2) : OOB;
     }
 
     const int Ct = a.C0 + a.C1;
     const int nk = a.K / BK;
-    const int ldw = a.ldw ? a.ldw : a.K;
+    int tap = 0, cb = 0;  // (tap, channel base) of the NEXT stage to issue
 
-    uint4 xr[RP], wr[RQ];
-    int tap = 0, cb = 0;  // running (tap, channel base) of the NEXT k-step to load
-
-    auto gload = [&]() {
+    auto issue = [&](int stage) {
         int dy = 0, dx = 0;
         if (a.ksize == 3) { dy = tap / 3; dx = tap - dy * 3; }
-        const h16* sp; int ld, c;
-        if (cb < a.C0) { sp = src0; ld = a.ld0; c = cb; } else { sp = src1; ld = a.ld1; c = cb - a.C0; }
+        const bool s0 = cb < a.C0;
+        const __amdgpu_buffer_rsrc_t rs = s0 ? rs0 : rs1;
+        const int ld = s0 ? a.ld0 : a.ld1;
+        const int c = (s0 ? cb : cb - a.C0) + clog * 8;
         const int k0 = tap * Ct + cb;
+        char* sbase = smem_raw + (size_t)stage * (STAGE * 2) + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) {
+            const unsigned vo = (wbase[i] == OOB) ? OOB : wbase[i] + (unsigned)(k0 * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(sbase + i * (RPP * BK * 2)), 16, vo, 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
             int iy = iy0[i] + dy, ix = ix0[i] + dx;
-            bool ok = ((unsigned)iy < (unsigned)Hlog) && ((unsigned)ix < (unsigned)Wlog);
+            const bool ok = ((unsigned)iy < (unsigned)Hlog) && ((unsigned)ix < (unsigned)Wlog);
             if (a.ups) { iy >>= 1; ix >>= 1; }
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                size_t off = (size_t)(nb[i] + iy * a.Ws + ix) * (size_t)ld + (size_t)(c + c8 * 8);
-                v = *reinterpret_cast<const uint4*>(sp + off);
-            }
-            xr[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < RQ; ++i) {
-            int q = q0 + r0 + 32 * i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q < a.Q) v = *reinterpret_cast<const uint4*>(Wp + (size_t)q * ldw + k0 + c8 * 8);
-            wr[i] = v;
+            const unsigned vo = ok ? (unsigned)(((nb[i] + iy * a.Ws + ix) * ld + c) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sbase + (BQ * BK * 2) + i * (RPP * BK * 2)), 16, vo, 0, 0, 0);
         }
         cb += BK;
         if (cb >= Ct) { cb = 0; ++tap; }
     };
-    auto lstore = [&](int buf) {
-        h16* sW = smem + buf * BUF;
-        h16* sX = sW + BQ * BK;
-#pragma unroll
-        for (int i = 0; i < RQ; ++i) *reinterpret_cast<uint4*>(sW + (r0 + 32 * i) * BK + swz_chunk) = wr[i];
-#pragma unroll
-        for (int i = 0; i < RP; ++i) *reinterpret_cast<uint4*>(sX + (r0 + 32 * i) * BK + swz_chunk) = xr[i];
-    };
 
-    const int wave = tid >> 6, lane = tid & 63;
     const int wq = wave / WP, wp = wave % WP;
     const int l31 = lane & 31, hh = lane >> 5;
 
@@ -124,28 +161,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload();
-    lstore(0);
-    __syncthreads();
+    // ---- prologue: NST-1 stages in flight
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) issue(s);
 
+    constexpr int L = RQ + RP;  // DMA instructions per stage per wave
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload();
-        const h16* sW = smem + buf * BUF;
+        // my part of stage kt has landed (later stages may stay in flight), then rendezvous: every wave's part of stage kt is
+        // visible and every wave has finished reading the ring slot that is refilled next
+        if (NST == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + NST - 1 < nk) issue((kt + NST - 1) % NST);
+        const h16* sW = smem + (kt % NST) * STAGE;
         const h16* sX = sW + BQ * BK;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < NKK; ++kk) {
             const int chunk = kk * 2 + hh;
             h16x8 af[TQ], bf[TP];
 #pragma unroll
             for (int i = 0; i < TQ; ++i) {
-                int r = (wq * TQ + i) * 32 + l31;
-                af[i] = *reinterpret_cast<const h16x8*>(sW + swz(r, chunk));
+                const int r = (wq * TQ + i) * 32 + l31;
+                af[i] = *reinterpret_cast<const h16x8*>(sW + swz<BK>(r, chunk));
             }
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                int r = (wp * TP + j) * 32 + l31;
-                bf[j] = *reinterpret_cast<const h16x8*>(sX + swz(r, chunk));
+                const int r = (wp * TP + j) * 32 + l31;
+                bf[j] = *reinterpret_cast<const h16x8*>(sX + swz<BK>(r, chunk));
             }
 #pragma unroll
             for (int i = 0; i < TQ; ++i)
@@ -153,8 +195,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
                 for (int j = 0; j < TP; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
     }
 
     // ------------------------------------------------------------------------------------------
@@ -170,135 +210,273 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
     const bool rvec0 = a.res0 && ((a.ldr0 & 3) == 0);
     const bool rvec1 = a.res1 && ((a.ldr1 & 3) == 0);
 
+    // per-pixel quantities of this lane's TP pixel columns (compile-time indices: no scratch)
+    int pj[TP]; bool prow[TP]; float mkj[TP], pbj[TP];
+    static_for<0, TP>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        pj[j] = p0 + (wp * TP + j) * 32 + l31;
+        prow[j] = pj[j] < a.P;
+        mkj[j] = (prow[j] && a.mask) ? 1.f - (float)a.mask[pj[j]] : 1.f;
+        pbj[j] = (prow[j] && a.bias && a.bias_per_pixel) ? (float)a.bias[pj[j]] : 0.f;
+    });
+    // optional per-channel statistics of the OUTPUT (sum, sum of squares over this wave's TP*32 pixels) for the GroupNorm that
+    // consumes it: plain stores of partial rows, no atomics (deterministic); the launcher guarantees sample alignment
+    const bool want_stats = (a.stats != nullptr);
+
+    static_for<0, TQ>([&](auto Ic) {
+        constexpr int iu = decltype(Ic)::value;
+        constexpr int ig = (iu + 1 < TQ) ? iu + 1 : iu;
+        const bool iu_active = !(geglu && (iu & 1));  // GEGLU: 32-row blocks alternate u | g; g is consumed with its u block
+        float ssum[16], ssq[16];
 #pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        const int p = p0 + (wp * TP + j) * 32 + l31;
-        if (p >= a.P) continue;
-        float mk = 1.f;
-        if (a.mask) mk = 1.f - (float)a.mask[p];
-        float pbias = 0.f;
-        if (a.bias && a.bias_per_pixel) pbias = (float)a.bias[p];
-#pragma unroll
-        for (int i = 0; i < (geglu ? 1 : TQ); ++i) {
+        for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+        static_for<0, TP>([&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            const int p = pj[j];
+            const bool active = prow[j] && iu_active;
+            const float mk = mkj[j], pbias = pbj[j];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int qw = q0 + (wq * TQ + i) * 32 + 8 * g + 4 * hh;  // W-row index of reg 4g
-                int co;                                                   // output channel of reg 4g
-                if (geglu) co = (q0 + wq * TQ * 32) / 2 + 8 * g + 4 * hh; else co = qw;
-                if (co >= Qout) continue;
-                float v[4];
+                const int qw = q0 + (wq * TQ + iu) * 32 + 8 * g + 4 * hh;  // W-row index of reg 4g
+                const int co = geglu ? (qw - 4 * hh - 8 * g) / 2 + 8 * g + 4 * hh : qw;  // output channel of reg 4g
+                if (active && co < Qout) {
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[i][j][4 * g + e];
-                    if (a.bias_per_pixel) x += pbias;
-                    else if (a.bias && (qw + e) < a.Q) x += (float)a.bias[qw + e];
-                    if (geglu) {
-                        float gg = acc[TQ > 1 ? 1 : 0][j][4 * g + e];
-                        if (a.bias && (qw + 32 + e) < a.Q) gg += (float)a.bias[qw + 32 + e];
-                        x = x * gelu_f(gg);
-                    } else {
-                        if (rowadd && (co + e) < Qout) x += rowadd[co + e];
-                        if (a.act == LADI_ACT_SILU) x = silu_f(x);
-                        else if (a.act == LADI_ACT_GELU) x = gelu_f(x);
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[iu][j][4 * g + e];
+                        if (a.bias_per_pixel) x += pbias;
+                        else if (a.bias && (qw + e) < a.Q) x += (float)a.bias[qw + e];
+                        if (geglu) {
+                            float gg = acc[ig][j][4 * g + e];
+                            if (a.bias && (qw + 32 + e) < a.Q) gg += (float)a.bias[qw + 32 + e];
+                            x = x * gelu_f(gg);
+                        } else {
+                            if (rowadd && (co + e) < Qout) x += rowadd[co + e];
+                            if (a.act == LADI_ACT_SILU) x = silu_f(x);
+                            else if (a.act == LADI_ACT_GELU) x = gelu_f(x);
+                        }
+                        v[e] = x * a.out_scale;
                     }
-                    v[e] = x * a.out_scale;
-                }
-                const bool full = (co + 3 < Qout);
-                if (a.res0) {
-                    const h16* rp = a.res0 + zr + (size_t)p * a.ldr0 + co;
-                    if (full && rvec0) { h16x4 r = *reinterpret_cast<const h16x4*>(rp);
+                    const bool full = (co + 3 < Qout);
+                    if (a.res0) {
+                        const h16* rp = a.res0 + zr + (size_t)p * a.ldr0 + co;
+                        if (full && rvec0) { const h16x4 r = *reinterpret_cast<const h16x4*>(rp);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)r[e]; }
-                    else { for (int e = 0; e < 4; ++e) if (co + e < Qout) v[e] += (float)rp[e]; }
-                }
-                if (a.res1) {
-                    const h16* rp = a.res1 + zr + (size_t)p * a.ldr1 + co;
-                    if (full && rvec1) { h16x4 r = *reinterpret_cast<const h16x4*>(rp);
+                            for (int e = 0; e < 4; ++e) v[e] += (float)r[e]; }
+                        else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)r[e]; }
-                    else { for (int e = 0; e < 4; ++e) if (co + e < Qout) v[e] += (float)rp[e]; }
-                }
+                            for (int e = 0; e < 4; ++e) if (co + e < Qout) v[e] += (float)rp[e]; }
+                    }
+                    if (a.res1) {
+                        const h16* rp = a.res1 + zr + (size_t)p * a.ldr1 + co;
+                        if (full && rvec1) { const h16x4 r = *reinterpret_cast<const h16x4*>(rp);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= mk;
-                if (a.out_f32) {
-                    float* op = reinterpret_cast<float*>(a.out) + zo + (size_t)p * a.ldo + co;
-                    if (full && vec_ok) { *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]); }
-                    else { for (int e = 0; e < 4; ++e) if (co + e < Qout) op[e] = v[e]; }
-                } else {
-                    h16* op = reinterpret_cast<h16*>(a.out) + zo + (size_t)p * a.ldo + co;
-                    if (full && vec_ok) {
+                            for (int e = 0; e < 4; ++e) v[e] += (float)r[e]; }
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (co + e < Qout) v[e] += (float)rp[e]; }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= mk;
+                    if (a.out_f32) {
+                        float* op = reinterpret_cast<float*>(a.out) + zo + (size_t)p * a.ldo + co;
+                        if (full && vec_ok) { *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]); }
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (co + e < Qout) op[e] = v[e]; }
+                    } else {
+                        h16* op = reinterpret_cast<h16*>(a.out) + zo + (size_t)p * a.ldo + co;
                         h16x4 o; o[0] = (h16)v[0]; o[1] = (h16)v[1]; o[2] = (h16)v[2]; o[3] = (h16)v[3];
-                        *reinterpret_cast<h16x4*>(op) = o;
-                    } else { for (int e = 0; e < 4; ++e) if (co + e < Qout) op[e] = (h16)v[e]; }
+                        if (full && vec_ok) { *reinterpret_cast<h16x4*>(op) = o; }
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (co + e < Qout) op[e] = o[e]; }
+                        if (want_stats) {   // statistics of the values as stored (fp16-rounded)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float r = (co + e < Qout) ? (float)o[e] : 0.f;
+                                ssum[4 * g + e] += r; ssq[4 * g + e] += r * r;
+                            }
+                        }
+                    }
+                }
+            }
+        });
+        if (want_stats && iu_active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) { ssum[r] += __shfl_xor(ssum[r], off); ssq[r] += __shfl_xor(ssq[r], off); }
+            }
+            if (l31 == 0) {
+                const size_t row = (size_t)pt * WP + wp;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = q0 + (wq * TQ + iu) * 32 + 8 * g + 4 * hh;
+                    float* sp = a.stats + (row * Qout + co) * 2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < Qout) { sp[2 * e] = ssum[4 * g + e]; sp[2 * e + 1] = ssq[4 * g + e]; }
                 }
             }
         }
-    }
+    });
 }
 
-template <int WQ, int WP, int TQ, int TP>
-int launch_cfg(const IGemmArgs& a, int batch, hipStream_t st) {
+struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; };
+// cfg 1..6 (0 = auto)
+constexpr int NCFG = 10;
+const CfgInfo kCfg[NCFG + 1] = {
+    {0, 0, 0, false, 0.f, 0},
+    {128, 256, 2, true, 0.80f, 4},   // 1: <2,2,2,4> BK32 NST3
+    {320, 128, 2, false, 1.00f, 2},  // 2: <2,2,5,2> BK32 NST2 (Cout = 320 layers, no padding waste)
+    {128, 128, 3, true, 1.00f, 2},   // 3: <2,2,2,2> BK32 NST3
+    {128, 64, 4, true, 0.80f, 1},    // 4: <2,2,2,1> BK32 NST3
+    {64, 64, 6, false, 0.60f, 1},    // 5: <2,2,1,1> BK32 NST3
+    {256, 128, 2, true, 0.85f, 2},   // 6: <2,2,4,2> BK32 NST3
+    {128, 128, 2, true, 0.00f, 2},   // 7: <2,2,2,2> BK64 NST2   (eff 0: experimental, never auto-selected)
+    {128, 256, 1, true, 0.00f, 4},   // 8: <2,2,2,4> BK64 NST2
+    {128, 64, 2, true, 0.00f, 1},    // 9: <2,2,2,1> BK64 NST3
+    {320, 128, 1, false, 0.00f, 2},  // 10: <2,2,5,2> BK64 NST2
+};
+
+template <int WQ, int WP, int TQ, int TP, int BK, int NST>
+int launch_cfg(IGemmArgs a, int batch, hipStream_t st) {
     constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
-    constexpr int SMEM = 2 * (BQ + BP) * BK * (int)sizeof(h16);
+    constexpr int SMEM = NST * (BQ + BP) * BK * (int)sizeof(h16);
     static bool attr_set = false;
-    auto kfn = igemm_kernel<WQ, WP, TQ, TP>;
+    auto kfn = igemm_kernel<WQ, WP, TQ, TP, BK, NST>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
             return -10;
         attr_set = true;
     }
     const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
-    dim3 grid((unsigned)(nq * np), 1, (unsigned)batch);
+    int blocks = nq * np;
+    a.tile_map = 0;
+    if (batch == 1) {
+        if (np >= 16) { a.tile_map = 1; blocks = 8 * ((np + 7) / 8) * nq; }
+        else if (nq >= 16) { a.tile_map = 2; blocks = 8 * ((nq + 7) / 8) * np; }
+    }
+    dim3 grid((unsigned)blocks, 1, (unsigned)batch);
     hipLaunchKernelGGL(kfn, grid, dim3(256), SMEM, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 
-}  // namespace
-
-#include <vector>
-namespace {
-struct ProfRec { hipEvent_t e0, e1; int cfg; double flops; };
+struct ProfRec { hipEvent_t e0, e1; int cfg; double flops; int P, Q, K, ks; };
 bool g_prof = false;
 std::vector<ProfRec> g_recs;
+
+struct TuneKey {
+    int P, Q, K, C0, C1, Wo, flags, batch;
+    bool operator==(const TuneKey& o) const {
+        return P == o.P && Q == o.Q && K == o.K && C0 == o.C0 && C1 == o.C1 && Wo == o.Wo && flags == o.flags && batch == o.batch;
+    }
+};
+struct TuneHash {
+    size_t operator()(const TuneKey& k) const {
+        size_t h = 1469598103934665603ULL;
+        const int v[8] = {k.P, k.Q, k.K, k.C0, k.C1, k.Wo, k.flags, k.batch};
+        for (int x : v) { h ^= (size_t)(unsigned)x; h *= 1099511628211ULL; }
+        return h;
+    }
+};
+bool g_autotune = true;
+std::unordered_map<TuneKey, int, TuneHash> g_tuned;
+
 }  // namespace
 
-// Tile-shape choice. cfg: 0 = auto, 1 = Q128xP128, 2 = Q64xP256, 3 = Q64xP64, 4 = Q128xP64
-int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st) {
+int ladi_igemm_num_cfgs() { return NCFG; }
+
+int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st, int* stats_row_px) {
+    IGemmArgs a = a_in;
+    if (stats_row_px) *stats_row_px = 0;
     if (a.ksize != 1 && a.ksize != 3) return -1;
-    if ((a.C0 % BK) || (a.C1 % BK)) return -2;
+    if ((a.C0 % 32) || (a.C1 % 32)) return -2;
     if (a.K != a.ksize * a.ksize * (a.C0 + a.C1)) return -3;
     if ((a.ld0 % 8) || (a.C1 && (a.ld1 % 8)) || (a.K % 8) || (a.ldw % 8)) return -4;
     if (a.P <= 0 || a.Q <= 0) return -5;
     const bool geglu = a.act == LADI_ACT_GEGLU;
     if (geglu && (a.Q % 64)) return -6;
-    if (cfg == 0) {
-        auto tiles = [&](int bq, int bp) { return (long long)((a.Q + bq - 1) / bq) * ((a.P + bp - 1) / bp) * batch; };
-        auto waste = [&](int bq, int bp) {
-            double padded = (double)((a.Q + bq - 1) / bq * bq) * ((a.P + bp - 1) / bp * bp);
-            return padded / ((double)a.Q * a.P);
-        };
-        // prefer big tiles when they fill the chip (>= 2 blocks on each of 256 CUs) without padding waste
-        if (waste(128, 128) < 1.05 && tiles(128, 128) >= 384) cfg = 1;
-        else if (waste(64, 256) < 1.05 && tiles(64, 256) >= 384) cfg = 2;
-        else if (waste(128, 64) < 1.10 && tiles(128, 64) >= 256) cfg = 4;
-        else if (geglu) cfg = (waste(128, 64) <= waste(64, 256)) ? 4 : 2;
-        else cfg = 3;
+    // ---- measured tile-shape selection ("measure, don't guess"): the first time a problem shape is seen outside a stream
+    //      capture, every admissible configuration is timed with HIP events on the launch stream and the fastest is cached.
+    //      Re-running a launch is idempotent (outputs never alias inputs in this library).
+    TuneKey key{a.P, a.Q, a.K, a.C0, a.C1, a.Wo, (a.ksize << 8) | (a.stride << 4) | (a.ups << 2) | (geglu ? 1 : 0), batch};
+    if (cfg == 0 && g_autotune) {
+        auto it = g_tuned.find(key);
+        if (it != g_tuned.end()) cfg = it->second;
+        else {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone && !g_prof) {
+                const bool was = g_autotune;
+                g_autotune = false;
+                hipEvent_t e0, e1;
+                if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                    float best_ms = 1e30f; int best_cfg = 0;
+                    for (int c = 1; c <= NCFG; ++c) {
+                        if (kCfg[c].blocks_per_cu < 2) continue;                       // 1-block/CU shapes never won
+                        if (geglu && !kCfg[c].geglu_ok) continue;
+                        if (c >= 7 && ((a.C0 % 64) || (a.C1 % 64))) continue;
+                        if (kCfg[c].bq > 2 * a.Q && kCfg[c].bq > 64) continue;        // grossly oversized in Q
+                        if (ladi_launch_igemm(a, batch, c, st) != 0) continue;          // warm-up (also sets function attributes)
+                        (void)hipEventRecord(e0, st);
+                        for (int r = 0; r < 3; ++r) (void)ladi_launch_igemm(a, batch, c, st);
+                        (void)hipEventRecord(e1, st);
+                        if (hipEventSynchronize(e1) != hipSuccess) continue;
+                        float ms = 0.f;
+                        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best_cfg = c; }
+                    }
+                    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+                    if (best_cfg) { g_tuned[key] = best_cfg; cfg = best_cfg; }
+                }
+                g_autotune = was;
+            }
+        }
     }
-    if (geglu && cfg == 3) cfg = 4;
+    if (cfg == 0) {
+        // fallback cost model: (waves of workgroups over the chip) x (tile work) / (per-tile efficiency)
+        double best = 1e300;
+        for (int c = 1; c <= NCFG; ++c) {
+            const CfgInfo& ci = kCfg[c];
+            if (geglu && !ci.geglu_ok) continue;
+            const long long tiles = (long long)((a.Q + ci.bq - 1) / ci.bq) * ((a.P + ci.bp - 1) / ci.bp) * batch;
+            const long long slots = 256LL * ci.blocks_per_cu;
+            const double waves = (double)((tiles + slots - 1) / slots);
+            // partial last wave: count it in proportion but never below 35% (a lone straggler still takes a full tile time)
+            const double frac = (double)(tiles % slots) / (double)slots;
+            const double eff_waves = (tiles % slots) ? (waves - 1.0) + (frac < 0.35 ? 0.35 : frac) : waves;
+            const double cost = eff_waves * (double)ci.bq * ci.bp * ci.blocks_per_cu / ci.eff;
+            if (cost < best) { best = cost; cfg = c; }
+        }
+    }
+    if (cfg < 1 || cfg > NCFG) return -7;
+    if (geglu && !kCfg[cfg].geglu_ok) return -8;
+    if (cfg >= 7 && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
+    if (a.stats) {  // fused output statistics need whole 32*TP-pixel row blocks inside one sample
+        const int px = kCfg[cfg].tp * 32;
+        if (geglu || batch != 1 || a.out_f32 || ((a.Ho * a.Wo) % px)) a.stats = nullptr;
+        else if (stats_row_px) *stats_row_px = px;
+    }
     ProfRec rec;
     const bool prof = g_prof;
     if (prof) {
         if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) return -12;
-        rec.cfg = cfg;
+        rec.cfg = cfg; rec.P = a.P; rec.Q = a.Q; rec.K = a.K; rec.ks = a.ksize;
         rec.flops = 2.0 * (double)a.P * (double)a.Q * (double)a.K * (double)batch;
         (void)hipEventRecord(rec.e0, st);
     }
     int rc;
     switch (cfg) {
-        case 1: rc = launch_cfg<2, 2, 2, 2>(a, batch, st); break;
-        case 2: rc = launch_cfg<1, 4, 2, 2>(a, batch, st); break;
-        case 3: rc = launch_cfg<2, 2, 1, 1>(a, batch, st); break;
-        case 4: rc = launch_cfg<2, 2, 2, 1>(a, batch, st); break;
+        case 1: rc = launch_cfg<2, 2, 2, 4, 32, 3>(a, batch, st); break;
+        case 2: rc = launch_cfg<2, 2, 5, 2, 32, 2>(a, batch, st); break;
+        case 3: rc = launch_cfg<2, 2, 2, 2, 32, 3>(a, batch, st); break;
+        case 4: rc = launch_cfg<2, 2, 2, 1, 32, 3>(a, batch, st); break;
+        case 5: rc = launch_cfg<2, 2, 1, 1, 32, 3>(a, batch, st); break;
+        case 6: rc = launch_cfg<2, 2, 4, 2, 32, 3>(a, batch, st); break;
+        case 7: rc = launch_cfg<2, 2, 2, 2, 64, 2>(a, batch, st); break;
+        case 8: rc = launch_cfg<2, 2, 2, 4, 64, 2>(a, batch, st); break;
+        case 9: rc = launch_cfg<2, 2, 2, 1, 64, 3>(a, batch, st); break;
+        case 10: rc = launch_cfg<2, 2, 5, 2, 64, 2>(a, batch, st); break;
         default: rc = -7;
     }
     if (prof) { (void)hipEventRecord(rec.e1, st); g_recs.push_back(rec); }
@@ -307,17 +485,23 @@ int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st) {
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream around every igemm launch
 void ladi_igemm_profile_enable(int on) { g_prof = on != 0; }
-// out[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP (2*P*Q*K), launches} for cfg 1..4 (index 0 = all); clears the records
-int ladi_igemm_profile_collect(double* out15) {
-    for (int i = 0; i < 15; ++i) out15[i] = 0.0;
+void ladi_igemm_autotune(int on) { g_autotune = on != 0; }
+int ladi_igemm_tuned_count() { return (int)g_tuned.size(); }
+// out[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP (2*P*Q*K), launches} for cfg 1..NCFG (index 0 = all); clears the records
+int ladi_igemm_profile_collect(double* out, int n_out) {
+    for (int i = 0; i < n_out; ++i) out[i] = 0.0;
+    std::map<std::string, std::pair<double, int>> by_shape;
+    const bool dump = getenv("LADI_PROF_DUMP") != nullptr;
     for (auto& r : g_recs) {
         if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return -2;
-        out15[r.cfg * 3 + 0] += ms; out15[r.cfg * 3 + 1] += r.flops; out15[r.cfg * 3 + 2] += 1.0;
-        out15[0] += ms; out15[1] += r.flops; out15[2] += 1.0;
+        if (r.cfg * 3 + 2 < n_out) { out[r.cfg * 3 + 0] += ms; out[r.cfg * 3 + 1] += r.flops; out[r.cfg * 3 + 2] += 1.0; }
+        out[0] += ms; out[1] += r.flops; out[2] += 1.0;
+        if (dump) { char b[128]; snprintf(b, sizeof(b), "P=%d Q=%d K=%d ks=%d cfg=%d gflop=%.1f", r.P, r.Q, r.K, r.ks, r.cfg, r.flops / 1e9); auto& e = by_shape[b]; e.first += ms; e.second += 1; }
         (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     g_recs.clear();
+    if (dump) for (auto& kv : by_shape) fprintf(stderr, "[igemm-prof] %-60s calls=%3d total_ms=%8.3f avg_us=%8.1f\n", kv.first.c_str(), kv.second.second, kv.second.first, 1000.0 * kv.second.first / kv.second.second);
     return 0;
 }

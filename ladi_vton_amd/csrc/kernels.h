@@ -5,16 +5,20 @@
 #include "common.h"
 
 // ---- igemm.hip
-int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st);
+// a.stats (optional): per-channel partial statistics of the output, [ceil(P / px)][Q][2] floats (sum, sumsq) where px =
+// *stats_row_px pixels per row (a multiple of 32 chosen with the tile shape; 0 = not produced, use ladi_launch_gn_partial)
+int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st, int* stats_row_px = nullptr);
 
 // ---- norm.hip
-// GroupNorm statistics over the virtual channel-concat of (src0[C0], src1[C1]); stats[n][G][2] += (sum, sumsq)
-int ladi_launch_gn_stats(const h16* src0, int C0, int ld0, const h16* src1, int C1, int ld1, int n, int HW, int groups,
-                         float* stats, hipStream_t st);
-// y = act(GN(x)) (+ add): out [n][HW][C0+C1] dense
-int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int C1, int ld1, int n, int HW, int groups,
-                         const float* stats, const h16* gamma, const h16* beta, float eps, int silu, const h16* add,
-                         h16* out, hipStream_t st);
+// GroupNorm in three stages (all atomics-free): per-channel partial statistics rows [rows][C][2] (written by the producing
+// igemm's epilogue, or by ladi_launch_gn_partial), finalize -> scale_shift[n][C0+C1][2], apply.
+int ladi_gn_partial_rows(int n, int HW, int C);   // rows per sample ladi_launch_gn_partial writes
+int ladi_launch_gn_partial(const h16* src, int C, int ld, int n, int HW, float* part, hipStream_t st);
+int ladi_launch_gn_finalize(const float* part0, int C0, int rps0, const float* part1, int C1, int rps1, int n, int HW, int groups,
+                            const h16* gamma, const h16* beta, float eps, float* scale_shift, hipStream_t st);
+// y = act(x * scale + shift) (+ add) over the virtual concat (src0[C0] | src1[C1]): out [n][HW][C0+C1] dense
+int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int C1, int ld1, int n, int HW,
+                         const float* scale_shift, int silu, const h16* add, h16* out, hipStream_t st);
 int ladi_launch_layernorm(const h16* x, int ldx, const h16* gamma, const h16* beta, float eps, int rows, int C, h16* out,
                           int ldo, hipStream_t st);
 // P[r][:] = softmax(scale * S[r][:]) ; S fp32 [rows][cols], P fp16
@@ -93,4 +97,6 @@ int ladi_launch_lat_pix_to_nchw(const float* src, int B, int hw, float* dst, hip
 
 // ---- igemm per-launch timing hooks (HIP events on the launch stream); see igemm.hip
 void ladi_igemm_profile_enable(int on);
-int ladi_igemm_profile_collect(double* out15);
+void ladi_igemm_autotune(int on);   // measured tile-shape selection on first use of a problem shape (default on)
+int ladi_igemm_tuned_count();
+int ladi_igemm_profile_collect(double* out, int n_out);

@@ -5,99 +5,157 @@
 
 namespace {
 
-constexpr int GN_PIX_PER_BLOCK = 64;
+// ------------------------------------------------------------------------------------------------
+// GroupNorm = per-channel partial statistics  ->  finalize (scale/shift per (n, c))  ->  apply.
+// Partial statistics are rows of [C][2] floats (sum, sum of squares) over a fixed number of pixels; they are normally written
+// by the PRODUCING igemm's epilogue (igemm.hip) and only by gn_partial_kernel when the producer could not (unaligned tiles).
+// No atomics anywhere: bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+constexpr int GN_MAX_C = 2560;
 
-// stats[n][g][0] += sum, [1] += sumsq over the virtual concat (src0 | src1), NHWC.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ src0, int C0, int ld0,
-                                                       const h16* __restrict__ src1, int C1, int ld1, int HW, int groups,
-                                                       float* __restrict__ stats) {
-    __shared__ float bins[4][64][2];  // per-wave private bins (groups <= 64)
-    const int tid = threadIdx.x, wave = tid >> 6;
-    for (int i = tid; i < 4 * 64 * 2; i += 256) (&bins[0][0][0])[i] = 0.f;
-    __syncthreads();
-    const int n = blockIdx.y;
-    const int Ct = C0 + C1;
-    const int octs = Ct >> 3;
-    const int gs = Ct / groups;
-    const int pix0 = blockIdx.x * GN_PIX_PER_BLOCK;
-    const int npix = min(GN_PIX_PER_BLOCK, HW - pix0);
-    const int total = npix * octs;
-    for (int idx = tid; idx < total; idx += 256) {
-        const int pix = idx / octs, oc = idx - pix * octs;
-        const int c = oc << 3;
-        const size_t row = (size_t)n * HW + pix0 + pix;
-        h16x8 v;
-        if (c < C0) v = *reinterpret_cast<const h16x8*>(src0 + row * ld0 + c);
-        else v = *reinterpret_cast<const h16x8*>(src1 + row * ld1 + (c - C0));
-        int g = c / gs;
-        int gend = (g + 1) * gs;  // first channel of next group
-        float s = 0.f, ss = 0.f;
+// fallback producer: block (b, n) reduces pixels [b*ppb, (b+1)*ppb) of sample n for all channels -> part[(n*nb + b)][C][2]
+__global__ __launch_bounds__(256) void gn_partial_kernel(const h16* __restrict__ src, int C, int ld, int HW, int ppb,
+                                                         float* __restrict__ part) {
+    __shared__ float red[2 * (GN_MAX_C > 2048 ? GN_MAX_C : 2048)];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y, nb = gridDim.x;
+    const int octs = C >> 3;
+    const int to = octs < 256 ? octs : 256;   // octets handled concurrently
+    const int pl = 256 / to;                  // pixel lanes
+    const int my_o = tid % to, my_p = tid / to;
+    const int pix0 = blockIdx.x * ppb;
+    const int npix = min(ppb, HW - pix0);
+    const size_t row0 = (size_t)n * HW + pix0;
+    float* rsum = red;
+    float* rsq = red + (GN_MAX_C > 2048 ? GN_MAX_C : 2048);
+    for (int oc0 = 0; oc0 < octs; oc0 += to) {
+        const int oc = oc0 + my_o;
+        float s[8], q[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (c + e >= gend) {
-                atomicAdd(&bins[wave][g][0], s); atomicAdd(&bins[wave][g][1], ss);
-                s = 0.f; ss = 0.f; ++g; gend += gs;
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        if (my_p < pl && oc < octs) {
+            const h16* base = src + (oc << 3);
+            int p = my_p;
+            for (; p + pl < npix; p += 2 * pl) {   // two independent loads in flight
+                const h16x8 v0 = *reinterpret_cast<const h16x8*>(base + (row0 + p) * ld);
+                const h16x8 v1 = *reinterpret_cast<const h16x8*>(base + (row0 + p + pl) * ld);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float x = (float)v0[e], y = (float)v1[e]; s[e] += x + y; q[e] += x * x + y * y; }
             }
-            float x = (float)v[e];
-            s += x; ss += x * x;
+            for (; p < npix; p += pl) {
+                const h16x8 v0 = *reinterpret_cast<const h16x8*>(base + (row0 + p) * ld);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float x = (float)v0[e]; s[e] += x; q[e] += x * x; }
+            }
         }
-        atomicAdd(&bins[wave][g][0], s); atomicAdd(&bins[wave][g][1], ss);
-    }
-    __syncthreads();
-    if (tid < groups * 2) {
-        const int g = tid >> 1, w = tid & 1;
-        float t = bins[0][g][w] + bins[1][g][w] + bins[2][g][w] + bins[3][g][w];
-        atomicAdd(&stats[((size_t)n * groups + g) * 2 + w], t);
+        // combine the pixel lanes through LDS: slot [my_p][channel within this octet chunk]
+        __syncthreads();
+        if (my_p < pl && oc < octs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { rsum[(my_p * to + my_o) * 8 + e] = s[e]; rsq[(my_p * to + my_o) * 8 + e] = q[e]; }
+        }
+        __syncthreads();
+        const int nch = min(to, octs - oc0) * 8;
+        for (int cc = tid; cc < nch; cc += 256) {
+            float ts = 0.f, tq = 0.f;
+            for (int l = 0; l < pl; ++l) { ts += rsum[l * to * 8 + cc]; tq += rsq[l * to * 8 + cc]; }
+            float* o = part + (((size_t)n * nb + blockIdx.x) * C + (oc0 << 3) + cc) * 2;
+            o[0] = ts; o[1] = tq;
+        }
     }
 }
 
+// one block per sample: scale_shift[n][c] = (gamma*rstd, beta - mean*gamma*rstd) for GroupNorm over the virtual concat (C0 | C1)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part0, int C0, int rps0,
+                                                          const float* __restrict__ part1, int C1, int rps1, int HW, int groups,
+                                                          const h16* __restrict__ gamma, const h16* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale_shift) {
+    __shared__ float csum[GN_MAX_C], csq[GN_MAX_C];
+    __shared__ float gmean[64], grstd[64];
+    const int tid = threadIdx.x, n = blockIdx.x;
+    const int Ct = C0 + C1;
+    const int gs = Ct / groups;
+    for (int c = tid; c < Ct; c += 256) {
+        const float* p; int C, rps, cl;
+        if (c < C0) { p = part0; C = C0; rps = rps0; cl = c; } else { p = part1; C = C1; rps = rps1; cl = c - C0; }
+        const float2* row = reinterpret_cast<const float2*>(p) + (size_t)n * rps * C + cl;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+        int r = 0;
+        for (; r + 1 < rps; r += 2) {
+            const float2 a = row[(size_t)r * C], b = row[(size_t)(r + 1) * C];
+            s0 += a.x; q0 += a.y; s1 += b.x; q1 += b.y;
+        }
+        if (r < rps) { const float2 a = row[(size_t)r * C]; s0 += a.x; q0 += a.y; }
+        csum[c] = s0 + s1; csq[c] = q0 + q1;
+    }
+    __syncthreads();
+    if (tid < groups) {
+        float s = 0.f, q = 0.f;
+        for (int c = tid * gs; c < (tid + 1) * gs; ++c) { s += csum[c]; q += csq[c]; }
+        const float inv = 1.f / ((float)gs * (float)HW);
+        const float mean = s * inv;
+        const float var = fmaxf(q * inv - mean * mean, 0.f);
+        gmean[tid] = mean; grstd[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < Ct; c += 256) {
+        const int g = c / gs;
+        const float ga = (float)gamma[c] * grstd[g];
+        reinterpret_cast<float2*>(scale_shift)[(size_t)n * Ct + c] = make_float2(ga, (float)beta[c] - gmean[g] * ga);
+    }
+}
+
+// y = act(x * scale + shift) (+ add): pure streaming, no LDS, no block-level setup
 __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ src0, int C0, int ld0,
-                                                       const h16* __restrict__ src1, int C1, int ld1, int HW, int groups,
-                                                       const float* __restrict__ stats, const h16* __restrict__ gamma,
-                                                       const h16* __restrict__ beta, float eps, int silu,
+                                                       const h16* __restrict__ src1, int C1, int ld1, int HW,
+                                                       const float* __restrict__ scale_shift, int silu,
                                                        const h16* __restrict__ add, h16* __restrict__ out, int pix_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float sc_sh[];  // [Ct] scale, [Ct] shift
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int Ct = C0 + C1;
-    const int gs = Ct / groups;
-    float* scale = sc_sh;
-    float* shift = sc_sh + Ct;
-    const float inv_cnt = 1.f / ((float)gs * (float)HW);
-    for (int c = tid; c < Ct; c += 256) {
-        const int g = c / gs;
-        const float s = stats[((size_t)n * groups + g) * 2 + 0];
-        const float ss = stats[((size_t)n * groups + g) * 2 + 1];
-        const float mean = s * inv_cnt;
-        const float var = fmaxf(ss * inv_cnt - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + eps);
-        const float ga = (float)gamma[c] * rstd;
-        scale[c] = ga;
-        shift[c] = (float)beta[c] - mean * ga;
-    }
-    __syncthreads();
     const int octs = Ct >> 3;
+    const int to = octs < 256 ? octs : 256;
+    const int pl = 256 / to;
+    const int my_o = tid % to, my_p = tid / to;
+    if (my_p >= pl) return;
     const int pix0 = blockIdx.x * pix_per_block;
     const int npix = min(pix_per_block, HW - pix0);
-    const int total = npix * octs;
-    for (int idx = tid; idx < total; idx += 256) {
-        const int pix = idx / octs, oc = idx - pix * octs;
+    const size_t row0 = (size_t)n * HW + pix0;
+    for (int oc = my_o; oc < octs; oc += to) {
         const int c = oc << 3;
-        const size_t row = (size_t)n * HW + pix0 + pix;
-        h16x8 v;
-        if (c < C0) v = *reinterpret_cast<const h16x8*>(src0 + row * ld0 + c);
-        else v = *reinterpret_cast<const h16x8*>(src1 + row * ld1 + (c - C0));
-        h16x8 o;
-        h16x8 ad;
-        if (add) ad = *reinterpret_cast<const h16x8*>(add + row * Ct + c);
+        const h16* base; int ld;
+        if (c < C0) { base = src0 + c; ld = ld0; } else { base = src1 + (c - C0); ld = ld1; }
+        float sc[8], sh[8];
+        {
+            const float4* ss = reinterpret_cast<const float4*>(scale_shift + ((size_t)n * Ct + c) * 2);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float y = (float)v[e] * scale[c + e] + shift[c + e];
-            if (silu) y = silu_f(y);
-            if (add) y += (float)ad[e];
-            o[e] = (h16)y;
+            for (int e = 0; e < 4; ++e) { const float4 t = ss[e]; sc[2 * e] = t.x; sh[2 * e] = t.y; sc[2 * e + 1] = t.z; sh[2 * e + 1] = t.w; }
         }
-        *reinterpret_cast<h16x8*>(out + row * Ct + c) = o;
+        auto xform = [&](const h16x8& v, const size_t row) {
+            h16x8 o;
+            h16x8 ad;
+            if (add) ad = *reinterpret_cast<const h16x8*>(add + row * Ct + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = (float)v[e] * sc[e] + sh[e];
+                if (silu) y = silu_f(y);
+                if (add) y += (float)ad[e];
+                o[e] = (h16)y;
+            }
+            *reinterpret_cast<h16x8*>(out + row * Ct + c) = o;
+        };
+        int p = my_p;
+        for (; p + 3 * pl < npix; p += 4 * pl) {   // four independent 16-byte loads in flight
+            const h16x8 v0 = *reinterpret_cast<const h16x8*>(base + (row0 + p) * ld);
+            const h16x8 v1 = *reinterpret_cast<const h16x8*>(base + (row0 + p + pl) * ld);
+            const h16x8 v2 = *reinterpret_cast<const h16x8*>(base + (row0 + p + 2 * pl) * ld);
+            const h16x8 v3 = *reinterpret_cast<const h16x8*>(base + (row0 + p + 3 * pl) * ld);
+            xform(v0, row0 + p); xform(v1, row0 + p + pl); xform(v2, row0 + p + 2 * pl); xform(v3, row0 + p + 3 * pl);
+        }
+        for (; p < npix; p += pl) {
+            const h16x8 v0 = *reinterpret_cast<const h16x8*>(base + (row0 + p) * ld);
+            xform(v0, row0 + p);
+        }
     }
 }
 
@@ -187,28 +245,42 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
+// pixels per block so that the grid has >= ~4 blocks per CU without making blocks tiny
+inline int pick_ppb(int n, int HW, int octs) {
+    int ppb = 4096 * 8 / (octs > 0 ? octs : 1);   // ~32K octets (512 KB) per block
+    if (ppb < 32) ppb = 32;
+    while (ppb > 48 && (long long)n * ((HW + ppb - 1) / ppb) < 768) ppb >>= 1;
+    return ppb;
+}
+
 }  // namespace
 
-int ladi_launch_gn_stats(const h16* src0, int C0, int ld0, const h16* src1, int C1, int ld1, int n, int HW, int groups,
-                         float* stats, hipStream_t st) {
-    const int Ct = C0 + C1;
-    if ((C0 & 7) || (C1 & 7) || groups > 64 || (Ct % groups) || (ld0 & 7) || (C1 && (ld1 & 7))) return -1;
-    dim3 grid((HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK, n);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, src0, C0, ld0, src1, C1, ld1, HW, groups, stats);
+int ladi_gn_partial_rows(int n, int HW, int C) { return (HW + pick_ppb(n, HW, C >> 3) - 1) / pick_ppb(n, HW, C >> 3); }
+
+int ladi_launch_gn_partial(const h16* src, int C, int ld, int n, int HW, float* part, hipStream_t st) {
+    if ((C & 7) || (ld & 7) || C > GN_MAX_C) return -1;
+    const int ppb = pick_ppb(n, HW, C >> 3);
+    dim3 grid((HW + ppb - 1) / ppb, n);
+    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(256), 0, st, src, C, ld, HW, ppb, part);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 
-int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int C1, int ld1, int n, int HW, int groups,
-                         const float* stats, const h16* gamma, const h16* beta, float eps, int silu, const h16* add,
-                         h16* out, hipStream_t st) {
+int ladi_launch_gn_finalize(const float* part0, int C0, int rps0, const float* part1, int C1, int rps1, int n, int HW, int groups,
+                            const h16* gamma, const h16* beta, float eps, float* scale_shift, hipStream_t st) {
     const int Ct = C0 + C1;
-    if ((C0 & 7) || (C1 & 7) || (Ct % groups) || (ld0 & 7) || (C1 && (ld1 & 7))) return -1;
-    // enough pixels per block to amortise the per-block scale/shift setup (Ct rsqrt's)
-    int ppb = 64;
-    while (ppb * (Ct >> 3) < 4096 && ppb < HW) ppb <<= 1;
+    if (groups > 64 || (Ct % groups) || Ct > GN_MAX_C) return -1;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, st, part0, C0, rps0, part1, C1, rps1, HW, groups, gamma, beta, eps,
+                       scale_shift);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int C1, int ld1, int n, int HW,
+                         const float* scale_shift, int silu, const h16* add, h16* out, hipStream_t st) {
+    const int Ct = C0 + C1;
+    if ((C0 & 7) || (C1 & 7) || (ld0 & 7) || (C1 && (ld1 & 7))) return -1;
+    const int ppb = pick_ppb(n, HW, Ct >> 3);
     dim3 grid((HW + ppb - 1) / ppb, n);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), (size_t)Ct * 2 * sizeof(float), st, src0, C0, ld0, src1, C1, ld1, HW,
-                       groups, stats, gamma, beta, eps, silu, add, out, ppb);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, st, src0, C0, ld0, src1, C1, ld1, HW, scale_shift, silu, add, out, ppb);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 

@@ -52,6 +52,8 @@ struct Arena {
 struct Act {  // NHWC fp16 activation view
     h16* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0, ld = 0;
+    // per-channel partial statistics written by the producing igemm (rows of st_px pixels, [rows][c][2] floats); st_px = 0: none
+    float* st_part = nullptr; int st_px = 0;
     size_t pixels() const { return (size_t)n * h * w; }
 };
 
@@ -85,6 +87,7 @@ struct ConvOpt {
     float out_scale = 1.f;
     int out_ld = 0;          // 0 -> cout (GEGLU: cout/2)
     int cfg = 0;             // igemm tile config override
+    bool stats = false;      // also produce per-channel partial statistics of the output (for a consuming GroupNorm)
 };
 
 DConv load_conv(DevPool& pool, const WeightStore& ws, const std::string& prefix, int cin_expected = -1);      // 4-D or 2-D weight
@@ -93,6 +96,10 @@ DConv load_geglu(DevPool& pool, const WeightStore& ws, const std::string& prefix
 DNorm load_norm(DevPool& pool, const WeightStore& ws, const std::string& prefix);
 
 Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& o);
+// output tensor + worst-case partial-statistics buffer (rows of 32 pixels) allocated together (stack discipline)
+Act new_act_with_stats(Ctx& c, int n, int h, int w, int cc);
+// launch an igemm whose output is `out` (pre-allocated), filling out.st_part / out.st_px when out.st_part != nullptr
+void launch_conv_into(Ctx& c, IGemmArgs& a, Act& out, int cfg = 0);
 Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups, float eps, int silu, const Act* add = nullptr);
 Act layer_norm(Ctx& c, const DNorm& nm, const Act& x, float eps);
 

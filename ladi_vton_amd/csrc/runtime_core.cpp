@@ -180,6 +180,25 @@ DNorm load_norm(DevPool& pool, const WeightStore& ws, const std::string& prefix)
 // ------------------------------------------------------------------------------------------------
 // op wrappers
 // ------------------------------------------------------------------------------------------------
+static float* alloc_part(Ctx& c, const Act& a) {   // worst case: rows of 32 pixels
+    return c.alloc_f32(((a.pixels() + 31) / 32) * (size_t)a.c * 2);
+}
+
+Act new_act_with_stats(Ctx& c, int n, int h, int w, int cc) {
+    Act a = c.new_act(n, h, w, cc);
+    a.st_part = alloc_part(c, a);
+    return a;
+}
+
+void launch_conv_into(Ctx& c, IGemmArgs& a, Act& out, int cfg) {
+    a.out = out.p; a.ldo = out.ld;
+    a.stats = (out.st_part && out.ld == out.c) ? out.st_part : nullptr;
+    int px = 0;
+    if (!c.dry()) c.check(ladi_launch_igemm(a, 1, cfg, c.st, &px), "igemm");
+    out.st_px = px;
+    if (!c.dry() && px == 0) out.st_part = nullptr;
+}
+
 Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& o) {
     const int pad = o.pad >= 0 ? o.pad : cv.k / 2;
     const int Hlog = o.ups ? 2 * x.h : x.h, Wlog = o.ups ? 2 * x.w : x.w;
@@ -191,7 +210,7 @@ Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& 
     const bool geglu = o.act == LADI_ACT_GEGLU;
     const int cout = geglu ? cv.cout / 2 : cv.cout;
     Act out = c.new_act(x.n, Ho, Wo, cout, o.out_ld);
-    if (c.dry()) return out;
+    if (o.stats && !geglu) out.st_part = alloc_part(c, out);
     IGemmArgs a;
     std::memset(&a, 0, sizeof(a));
     a.src0 = x.p; a.C0 = C0; a.ld0 = x.ld;
@@ -204,21 +223,39 @@ Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& 
     if (o.res0) { a.res0 = o.res0->p; a.ldr0 = o.res0->ld; }
     if (o.res1) { a.res1 = o.res1->p; a.ldr1 = o.res1->ld; }
     a.mask = o.mask;
-    a.out = out.p; a.ldo = out.ld; a.out_f32 = 0;
-    c.check(ladi_launch_igemm(a, 1, o.cfg, c.st), "igemm");
+    a.out_f32 = 0;
+    launch_conv_into(c, a, out, o.cfg);
     return out;
 }
 
+// GroupNorm over the virtual concat (x | x2): partial statistics come from the producers' epilogues when available
 Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups, float eps, int silu, const Act* add) {
     const int C0 = x.c, C1 = x2 ? x2->c : 0;
     if (C0 + C1 != nm.c) throw std::runtime_error("group_norm: channel mismatch");
-    Act out = c.new_act(x.n, x.h, x.w, C0 + C1);
-    float* stats = c.alloc_stats((size_t)x.n * groups * 2);
-    if (c.dry()) return out;
     const int HW = x.h * x.w;
-    c.check(ladi_launch_gn_stats(x.p, C0, x.ld, x2 ? x2->p : nullptr, C1, x2 ? x2->ld : 0, x.n, HW, groups, stats, c.st), "gn_stats");
-    c.check(ladi_launch_gn_apply(x.p, C0, x.ld, x2 ? x2->p : nullptr, C1, x2 ? x2->ld : 0, x.n, HW, groups, stats, nm.g, nm.b, eps,
-                                 silu, add ? add->p : nullptr, out.p, c.st), "gn_apply");
+    Act out = c.new_act(x.n, x.h, x.w, C0 + C1);
+    float* ss = c.alloc_f32((size_t)x.n * (C0 + C1) * 2);
+    const Act* srcs[2] = {&x, x2};
+    const float* part[2] = {nullptr, nullptr};
+    int rps[2] = {0, 0};
+    for (int i = 0; i < 2; ++i) {
+        const Act* s = srcs[i];
+        if (!s) continue;
+        // the fallback buffer is reserved unconditionally so that the planning pass and the real pass allocate identically
+        const int rows = ladi_gn_partial_rows(s->n, HW, s->c);
+        float* p = c.alloc_f32((size_t)s->n * rows * s->c * 2);
+        if (s->st_part && s->st_px > 0) {
+            part[i] = s->st_part;
+            rps[i] = HW / s->st_px;
+        } else {
+            if (!c.dry()) c.check(ladi_launch_gn_partial(s->p, s->c, s->ld, s->n, HW, p, c.st), "gn_partial");
+            part[i] = p; rps[i] = rows;
+        }
+    }
+    if (c.dry()) return out;
+    c.check(ladi_launch_gn_finalize(part[0], C0, rps[0], part[1], C1, rps[1], x.n, HW, groups, nm.g, nm.b, eps, ss, c.st), "gn_finalize");
+    c.check(ladi_launch_gn_apply(x.p, C0, x.ld, x2 ? x2->p : nullptr, C1, x2 ? x2->ld : 0, x.n, HW, ss, silu, add ? add->p : nullptr, out.p,
+                                 c.st), "gn_apply");
     return out;
 }
 

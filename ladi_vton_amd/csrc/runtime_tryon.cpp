@@ -106,7 +106,7 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
             const size_t mk_persist = arena.mark();
 
             if (!c.dry()) {
-                HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
+                if (stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
                 // prompt embeddings [uncond ; cond] (tryon_pipe.py:620-628)
                 const size_t pe = (size_t)B * L * D * sizeof(h16);
                 if (cfgf) {
@@ -141,7 +141,7 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
             // ---------------- 7. masked-image latents (RNG draw #3) + EMASC skips
             {
                 Act feats[5];
-                if (!c.dry()) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
+                if (!c.dry()) if (stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
                 c.stats_off = 0;
                 Act mom = vae->encode(c, masked_img, feats);
                 if (!c.dry()) c.check(ladi_launch_posterior_sample(mom.p, mom.ld, in.noise_masked, B, hw, vae->cfg.scaling_factor, masked_lat, st), "posterior");
@@ -165,7 +165,7 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
             auto one_step = [&]() {
                 arena.release(mk_loop);
                 c.stats_off = 0;
-                if (!c.dry()) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
+                if (!c.dry()) if (stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
                 Act eps = unet->forward(c, unet_in, unet->temb_table, d_step);
                 if (!c.dry()) { sa.eps = eps.p; sa.ld_eps = eps.ld; c.check(ladi_launch_sched_step(sa, st), "sched_step"); }
             };
@@ -197,7 +197,7 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
             {
                 Act z = c.new_act(B, h, w, 64);
                 if (!c.dry()) {
-                    HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
+                    if (stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
                     c.check(ladi_launch_post_quant(latents, vae->d_pq, 1.0f / vae->cfg.scaling_factor, B * hw, z.p, 64, st), "post_quant");
                 }
                 c.stats_off = 0;

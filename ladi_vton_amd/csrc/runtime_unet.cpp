@@ -147,10 +147,10 @@ struct Fwd {
     Act res(const ResBlock& r, const Act& x, const Act* x2) {
         Act out;
         // block output is allocated first so temporaries can be released (stack discipline)
-        out = c.new_act(x.n, x.h, x.w, r.cout);
+        out = new_act_with_stats(c, x.n, x.h, x.w, r.cout);
         const size_t mk = c.ar->mark();
         Act s1 = group_norm(c, r.n1, x, x2, u.cfg.groups, u.cfg.eps, 1);
-        ConvOpt o1; o1.rowadd = temb + r.temb_off; o1.rowadd_idx = tidx; o1.rowadd_stride = u.temb_total;
+        ConvOpt o1; o1.stats = true; o1.rowadd = temb + r.temb_off; o1.rowadd_idx = tidx; o1.rowadd_stride = u.temb_total;
         Act h1 = conv2d(c, r.c1, s1, nullptr, o1);
         Act s2 = group_norm(c, r.n2, h1, nullptr, u.cfg.groups, u.cfg.eps, 1);
         Act sc;
@@ -163,8 +163,7 @@ struct Fwd {
         return y;
     }
     // conv writing into a pre-allocated output
-    Act conv2d_into(const DConv& cv, const Act& x, ConvOpt o, const Act& out) {
-        if (c.dry()) return out;
+    Act conv2d_into(const DConv& cv, const Act& x, ConvOpt o, Act out) {
         IGemmArgs a; std::memset(&a, 0, sizeof(a));
         a.src0 = x.p; a.C0 = x.c; a.ld0 = x.ld;
         a.Hs = x.h; a.Ws = x.w; a.Ho = out.h; a.Wo = out.w; a.P = out.n * out.h * out.w;
@@ -173,8 +172,7 @@ struct Fwd {
         a.bias = cv.b; a.act = o.act; a.out_scale = 1.f;
         if (o.res0) { a.res0 = o.res0->p; a.ldr0 = o.res0->ld; }
         if (o.res1) { a.res1 = o.res1->p; a.ldr1 = o.res1->ld; }
-        a.out = out.p; a.ldo = out.ld;
-        c.check(ladi_launch_igemm(a, 1, 0, c.st), "igemm");
+        launch_conv_into(c, a, out);
         return out;
     }
     Act attn(const h16* q, int ldq, long long sq, const h16* k, const h16* v, int ldkv, long long skv, int n, int T, int Nk,
@@ -191,7 +189,7 @@ struct Fwd {
     }
     Act xf(const XfBlock& b, const Act& x) {
         const int n = x.n, T = x.h * x.w, C = b.C;
-        Act out = c.new_act(x.n, x.h, x.w, C);
+        Act out = new_act_with_stats(c, x.n, x.h, x.w, C);
         const size_t mk = c.ar->mark();
         Act g = group_norm(c, b.gn, x, nullptr, u.cfg.groups, 1e-6f, 0);
         Act tok = g; tok.h = T; tok.w = 1;  // tokens view [n][T][C]
@@ -215,7 +213,8 @@ struct Fwd {
         Act xin = x; xin.h = T; xin.w = 1;
         Act outv = out; outv.h = T; outv.w = 1;
         ConvOpt oo; oo.res0 = &xin;
-        conv2d_into(b.proj_out, t3, oo, outv);
+        outv = conv2d_into(b.proj_out, t3, oo, outv);
+        out.st_part = outv.st_part; out.st_px = outv.st_px;
         c.ar->release(mk);
         return out;
     }
@@ -228,7 +227,7 @@ Act UNet::forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_i
     Fwd f{c, *this, temb_row, temb_idx};
     const int L = cfg.layers_per_block;
     std::vector<Act> skips;
-    ConvOpt o;
+    ConvOpt o; o.stats = true;
     Act h = conv2d(c, conv_in, x, nullptr, o);
     skips.push_back(h);
     int ri = 0, xi = 0;
@@ -239,7 +238,7 @@ Act UNet::forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_i
             skips.push_back(h);
         }
         if (i < 3) {
-            ConvOpt od; od.stride = 2; od.pad = 1;
+            ConvOpt od; od.stride = 2; od.pad = 1; od.stats = true;
             h = conv2d(c, down_samp[i], h, nullptr, od);
             skips.push_back(h);
         }
@@ -255,7 +254,7 @@ Act UNet::forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_i
             if (i > 0) h = f.xf(up_xf[xi++], h);
         }
         if (i < 3) {
-            ConvOpt ou; ou.ups = 1;
+            ConvOpt ou; ou.ups = 1; ou.stats = true;
             h = conv2d(c, up_samp[i], h, nullptr, ou);
         }
     }

@@ -95,15 +95,15 @@ struct VF {
     Ctx& c; VAE& v;
     // ResnetBlock2D without time embedding; optional extra residual (EMASC skip folded into the producer epilogue)
     Act res(const ResBlock& r, const Act& x, const Act* extra) {
-        Act out = c.new_act(x.n, x.h, x.w, r.cout);
+        Act out = new_act_with_stats(c, x.n, x.h, x.w, r.cout);
         const size_t mk = c.ar->mark();
         Act s1 = group_norm(c, r.n1, x, nullptr, v.cfg.groups, v.cfg.eps, 1);
-        ConvOpt o1;
+        ConvOpt o1; o1.stats = true;
         Act h1 = conv2d(c, r.c1, s1, nullptr, o1);
         Act s2 = group_norm(c, r.n2, h1, nullptr, v.cfg.groups, v.cfg.eps, 1);
         Act sc; const Act* resid = &x;
         if (r.has_sc) { ConvOpt os; sc = conv2d(c, r.sc, x, nullptr, os); resid = &sc; }
-        if (!c.dry()) {
+        {
             IGemmArgs a; std::memset(&a, 0, sizeof(a));
             a.src0 = s2.p; a.C0 = s2.c; a.ld0 = s2.ld;
             a.Hs = x.h; a.Ws = x.w; a.Ho = x.h; a.Wo = x.w; a.P = (int)x.pixels();
@@ -111,8 +111,7 @@ struct VF {
             a.W = r.c2.w; a.Q = r.c2.cout; a.K = r.c2.K(); a.bias = r.c2.b; a.out_scale = 1.f;
             a.res0 = resid->p; a.ldr0 = resid->ld;
             if (extra) { a.res1 = extra->p; a.ldr1 = extra->ld; }
-            a.out = out.p; a.ldo = out.ld;
-            c.check(ladi_launch_igemm(a, 1, 0, c.st), "igemm");
+            launch_conv_into(c, a, out);
         }
         c.ar->release(mk);
         return out;
@@ -120,7 +119,7 @@ struct VF {
     // diffusers AttentionBlock (single head, d = C): materialised scores through three batched MFMA GEMMs
     Act attn(const VAEAttn& at, const Act& x) {
         const int n = x.n, T = x.h * x.w, C = at.C;
-        Act out = c.new_act(x.n, x.h, x.w, C);
+        Act out = new_act_with_stats(c, x.n, x.h, x.w, C);
         const size_t mk = c.ar->mark();
         Act g = group_norm(c, at.gn, x, nullptr, v.cfg.groups, v.cfg.eps, 0);
         Act tok = g; tok.h = T; tok.w = 1;
@@ -156,8 +155,8 @@ struct VF {
             std::memset(&a, 0, sizeof(a));
             a.src0 = o.p; a.C0 = C; a.ld0 = C; a.Hs = n * T; a.Ws = 1; a.Ho = n * T; a.Wo = 1; a.P = n * T;
             a.ksize = 1; a.stride = 1; a.W = at.proj.w; a.Q = C; a.K = at.proj.K(); a.bias = at.proj.b; a.out_scale = 1.f;
-            a.res0 = x.p; a.ldr0 = x.ld; a.out = out.p; a.ldo = out.ld;
-            c.check(ladi_launch_igemm(a, 1, 0, c.st), "igemm(proj)");
+            a.res0 = x.p; a.ldr0 = x.ld;
+            launch_conv_into(c, a, out);
         }
         c.ar->release(mk);
         return out;
@@ -169,7 +168,7 @@ struct VF {
 Act VAE::encode(Ctx& c, const Act& x, Act feats[5]) {
     VF f{c, *this};
     const int L = cfg.layers_per_block;
-    ConvOpt o;
+    ConvOpt o; o.stats = true;
     Act h = conv2d(c, e_conv_in, x, nullptr, o);
     feats[0] = h;  // idx1 (conv_in output)
     feats[1] = h;  // idx2 (input of down block 0) - same tensor (vae.py:104-109)
@@ -178,7 +177,7 @@ Act VAE::encode(Ctx& c, const Act& x, Act feats[5]) {
         if (i > 0) feats[i + 1] = h;  // input of down block i
         for (int j = 0; j < L; ++j) h = f.res(e_res[ri++], h, nullptr);
         if (i < 3) {
-            ConvOpt od; od.stride = 2; od.pad = 0;  // F.pad(0,1,0,1) + stride-2 conv, pad 0: trailing zeros via bounds check
+            ConvOpt od; od.stats = true; od.stride = 2; od.pad = 0;  // F.pad(0,1,0,1) + stride-2 conv, pad 0: trailing zeros via bounds check
             h = conv2d(c, e_down[i], h, nullptr, od);
         }
     }
@@ -193,7 +192,7 @@ Act VAE::encode(Ctx& c, const Act& x, Act feats[5]) {
 Act VAE::decode(Ctx& c, const Act& z, const Act* skips) {
     VF f{c, *this};
     const int L = cfg.layers_per_block;
-    ConvOpt o;
+    ConvOpt o; o.stats = true;
     Act h = conv2d(c, d_conv_in, z, nullptr, o);
     h = f.res(d_mid[0], h, nullptr);
     h = f.attn(d_attn, h);
@@ -203,7 +202,7 @@ Act VAE::decode(Ctx& c, const Act& z, const Act* skips) {
     for (int i = 0; i < 4; ++i) {
         for (int j = 0; j < L + 1; ++j) h = f.res(d_res[ri++], h, nullptr);
         if (i < 3) {
-            ConvOpt ou; ou.ups = 1;
+            ConvOpt ou; ou.ups = 1; ou.stats = true;
             if (skips) ou.res0 = &skips[3 - i];
             h = conv2d(c, d_up[i], h, nullptr, ou);
         }

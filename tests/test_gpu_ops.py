@@ -21,7 +21,7 @@ def _rand(shape, seed, scale=1.0):
 
 
 # --------------------------------------------------------------------------------------------------------------- igemm
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6])
 def test_mfma_layout_asymmetric(cfg):
     """transpose-detecting check of the MFMA fragment / accumulator mapping: 1x1 'conv' with an asymmetric weight."""
     N, H, W, C, Q = 1, 16, 24, 64, 192
@@ -36,7 +36,7 @@ def test_mfma_layout_asymmetric(cfg):
 
 
 @pytest.mark.parametrize("cin,cout,h,w,cfg", [(64, 64, 16, 12, 0), (128, 320, 24, 16, 0), (320, 128, 20, 12, 1), (192, 64, 32, 24, 2),
-                                              (64, 192, 9, 7, 3), (128, 128, 13, 5, 4)])
+                                              (64, 192, 9, 7, 3), (128, 128, 13, 5, 4), (64, 320, 17, 9, 2), (128, 256, 11, 7, 6), (192, 128, 16, 20, 5)])
 def test_conv3x3_bias_res_temb(cin, cout, h, w, cfg):
     N = 2
     x, wt, b = _rand((N, cin, h, w), 2), _rand((cout, cin, 3, 3), 3, 1 / math.sqrt(9 * cin)), _rand((cout,), 4, 0.1)
@@ -93,7 +93,7 @@ def test_conv_small_cin_cout_and_mask_silu():
     assert U.rel_l2(U.to_nchw(y, 3), ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 6])
 def test_linear_geglu(cfg):
     T, C = 200, 128
     x, w, b = _rand((1, C, T, 1), 26), _rand((8 * C, C), 27, 1 / math.sqrt(C)), _rand((8 * C,), 28, 0.1)

@@ -65,7 +65,7 @@ def run(name, n, H, W, cin, cout, k, cfg, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfgs", default="0,1,2,3,4")
+    ap.add_argument("--cfgs", default="0,1,2,3,4,5,6")
     ap.add_argument("--n", type=int, default=16)
     ap.add_argument("--vae-n", type=int, default=2)
     ap.add_argument("--iters", type=int, default=20)
