@@ -182,14 +182,15 @@ def main():
         lib.ladi_profile_igemm_enable(1)
         unet.time_forward(n, h, w, 1)   # 1 warm-up + 1 timed forward, both recorded
         lib.ladi_profile_igemm_enable(0)
-        prof = (ctypes.c_double * 33)()
-        lib.ladi_profile_igemm_collect(prof, 33)
+        prof = (ctypes.c_double * 51)()
+        lib.ladi_profile_igemm_collect(prof, 51)
         names = {1: "igemm_kernel<2,2,2,4,32,3> (Q128xP256)", 2: "igemm_kernel<2,2,5,2,32,2> (Q320xP128)", 3: "igemm_kernel<2,2,2,2,32,3> (Q128xP128)",
                  4: "igemm_kernel<2,2,2,1,32,3> (Q128xP64)", 5: "igemm_kernel<2,2,1,1,32,3> (Q64xP64)", 6: "igemm_kernel<2,2,4,2,32,3> (Q256xP128)"}
         per = {}
         names.update({7: "igemm_kernel<2,2,2,2,64,2> (Q128xP128 BK64)", 8: "igemm_kernel<2,2,2,4,64,2> (Q128xP256 BK64)", 9: "igemm_kernel<2,2,2,1,64,3> (Q128xP64 BK64)",
                       10: "igemm_kernel<2,2,5,2,64,2> (Q320xP128 BK64)"})
-        for c_ in range(1, 11):
+        names.update({11: "cfg9 + split-K 2", 12: "cfg9 + split-K 4", 13: "cfg9 + split-K 8", 14: "cfg7 + split-K 2", 15: "cfg7 + split-K 4"})
+        for c_ in range(1, 16):
             ms, fl, cnt = prof[c_ * 3], prof[c_ * 3 + 1], prof[c_ * 3 + 2]
             if cnt > 0:
                 per[c_] = dict(kernel=names[c_], launches=int(cnt), avg_ms=ms / cnt, flop_per_launch=fl / cnt, tflops=fl / ms / 1e9)

@@ -175,7 +175,7 @@ typedef struct {
     const void* W; int Q, K, ldw; long long bs_src0, bs_w, bs_out, bs_res;
     const void* bias; int bias_per_pixel; const float* rowadd; const int* rowadd_idx; int rowadd_stride; int act; float out_scale;
     const void* res0; const void* res1; int ldr0, ldr1; const void* mask; void* out; int ldo; int out_f32;
-    float* stats; int stats_groups; int tile_map /* ignored: set by the launcher */;
+    float* stats; int stats_groups; int splitk, tile_map /* both ignored: set by the launcher */;
 } ladi_igemm_desc;
 int ladi_op_igemm(const ladi_igemm_desc* d, int batch, int tile_cfg, void* stream);
 int ladi_op_group_norm(const void* src0, int C0, const void* src1, int C1, int n, int HW, int groups, const void* gamma,

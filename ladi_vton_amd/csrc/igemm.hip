@@ -88,11 +88,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmArgs a) {
     const int HsWs = a.Hs * a.Ws;
     const int n_first = p0 / HoWo;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<h16*>(a.src0 + (size_t)z * a.bs_src0 + (size_t)n_first * HsWs * a.ld0), 0, 0x7FFFFFFF, 0x00020000);
+        const_cast<h16*>(a.src0 + (a.splitk > 1 ? 0 : (size_t)z * a.bs_src0) + (size_t)n_first * HsWs * a.ld0), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<h16*>(a.src1 ? a.src1 + (size_t)n_first * HsWs * a.ld1 : a.src0), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<h16*>(a.W + (size_t)z * a.bs_w), 0, 0x7FFFFFFF, 0x00020000);
+        const_cast<h16*>(a.W + (a.splitk > 1 ? 0 : (size_t)z * a.bs_w)), 0, 0x7FFFFFFF, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
     // ---- per-thread pixel-row decode (constant over the K loop)
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmArgs a) {
         ix0[i] = ox * a.stride - a.pad;
         nb[i] = (n - n_first) * HsWs;
     }
+    const int Ct = a.C0 + a.C1;
     const int ldw = a.ldw ? a.ldw : a.K;
     unsigned wbase[RQ];
 #pragma unroll
@@ -120,9 +121,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmArgs a) {
         wbase[i] = (q < a.Q) ? (unsigned)(((size_t)q * ldw + clog * 8) * 2) : OOB;
     }
 
-    const int Ct = a.C0 + a.C1;
-    const int nk = a.K / BK;
+    // split-K: grid.z slices the K loop (a.splitk > 1); each slice writes an fp32 partial tile (see splitk_reduce_kernel)
+    int nk = a.K / BK;
     int tap = 0, cb = 0;  // (tap, channel base) of the NEXT stage to issue
+    if (a.splitk > 1) {
+        const int sps = (nk + a.splitk - 1) / a.splitk;
+        const int start = z * sps;
+        nk = max(0, min(sps, nk - start));
+        const int kb = start * BK;
+        tap = kb / Ct; cb = kb - tap * Ct;
+    }
 
     auto issue = [&](int stage) {
         int dy = 0, dx = 0;
@@ -381,21 +389,83 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmArgs a) {
     }
 }
 
-struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; };
+// ------------------------------------------------------------------------------------------------
+// split-K second pass: out = epilogue(sum_z part[z]) for problems with few output tiles and a deep K loop (the 8x6 level of the
+// UNet at batch 8 has only ~120 tiles for 256 CUs).  One block per 32 output pixels, threads own channels, pixels walked
+// sequentially -> coalesced rows and the same deterministic per-channel partial statistics rows as the fused epilogue.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, const IGemmArgs a) {
+    __shared__ float red[2][4][64];
+    const int p_base = blockIdx.x * 32;
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;   // 64 channels x 4 pixel lanes per block
+    const int c = blockIdx.y * 64 + cl;
+    const size_t slice = (size_t)a.P * a.Q;
+    const float* rowadd = a.rowadd;
+    if (rowadd && a.rowadd_idx) rowadd += (size_t)(*a.rowadd_idx) * a.rowadd_stride;
+    float ssum = 0.f, ssq = 0.f;
+    if (c < a.Q) {
+        const float b = (a.bias ? (float)a.bias[c] : 0.f) + (rowadd ? rowadd[c] : 0.f);
+        for (int r = pl; r < 32; r += 4) {
+            const int p = p_base + r;
+            if (p >= a.P) break;
+            float x = b;
+            for (int z = 0; z < S; ++z) x += part[(size_t)z * slice + (size_t)p * a.Q + c];
+            if (a.act == LADI_ACT_SILU) x = silu_f(x);
+            else if (a.act == LADI_ACT_GELU) x = gelu_f(x);
+            x = (float)(h16)(x * a.out_scale);   // same rounding point as the fused epilogue (fp16 before the residual add)
+            if (a.res0) x += (float)a.res0[(size_t)p * a.ldr0 + c];
+            if (a.res1) x += (float)a.res1[(size_t)p * a.ldr1 + c];
+            if (a.mask) x *= 1.f - (float)a.mask[p];
+            const h16 o = (h16)x;
+            reinterpret_cast<h16*>(a.out)[(size_t)p * a.ldo + c] = o;
+            const float q = (float)o;
+            ssum += q; ssq += q * q;
+        }
+    }
+    if (a.stats) {
+        red[0][pl][cl] = ssum; red[1][pl][cl] = ssq;
+        __syncthreads();
+        if (pl == 0 && c < a.Q) {
+            float* sp = a.stats + ((size_t)blockIdx.x * a.Q + c) * 2;
+            sp[0] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+            sp[1] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        }
+    }
+}
+
+float* g_ws = nullptr;
+size_t g_ws_bytes = 0;
+bool ensure_ws(size_t bytes, hipStream_t st) {
+    if (bytes <= g_ws_bytes) return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;  // cannot allocate in a capture
+    if (g_ws) (void)hipFree(g_ws);
+    g_ws = nullptr; g_ws_bytes = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&g_ws), bytes) != hipSuccess) return false;
+    g_ws_bytes = bytes;
+    return true;
+}
+
+struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; int base; int split; };
 // cfg 1..6 (0 = auto)
-constexpr int NCFG = 10;
+constexpr int NCFG = 15;
 const CfgInfo kCfg[NCFG + 1] = {
-    {0, 0, 0, false, 0.f, 0},
-    {128, 256, 2, true, 0.80f, 4},   // 1: <2,2,2,4> BK32 NST3
-    {320, 128, 2, false, 1.00f, 2},  // 2: <2,2,5,2> BK32 NST2 (Cout = 320 layers, no padding waste)
-    {128, 128, 3, true, 1.00f, 2},   // 3: <2,2,2,2> BK32 NST3
-    {128, 64, 4, true, 0.80f, 1},    // 4: <2,2,2,1> BK32 NST3
-    {64, 64, 6, false, 0.60f, 1},    // 5: <2,2,1,1> BK32 NST3
-    {256, 128, 2, true, 0.85f, 2},   // 6: <2,2,4,2> BK32 NST3
-    {128, 128, 2, true, 0.00f, 2},   // 7: <2,2,2,2> BK64 NST2   (eff 0: experimental, never auto-selected)
-    {128, 256, 1, true, 0.00f, 4},   // 8: <2,2,2,4> BK64 NST2
-    {128, 64, 2, true, 0.00f, 1},    // 9: <2,2,2,1> BK64 NST3
-    {320, 128, 1, false, 0.00f, 2},  // 10: <2,2,5,2> BK64 NST2
+    {0, 0, 0, false, 0.f, 0, 0, 1},
+    {128, 256, 2, true, 0.80f, 4, 1, 1},   // 1: <2,2,2,4> BK32 NST3
+    {320, 128, 2, false, 1.00f, 2, 2, 1},  // 2: <2,2,5,2> BK32 NST2 (Cout = 320 layers, no padding waste)
+    {128, 128, 3, true, 1.00f, 2, 3, 1},   // 3: <2,2,2,2> BK32 NST3
+    {128, 64, 4, true, 0.80f, 1, 4, 1},    // 4: <2,2,2,1> BK32 NST3
+    {64, 64, 6, false, 0.60f, 1, 5, 1},    // 5: <2,2,1,1> BK32 NST3
+    {256, 128, 2, true, 0.85f, 2, 6, 1},   // 6: <2,2,4,2> BK32 NST3
+    {128, 128, 2, true, 0.00f, 2, 7, 1},   // 7: <2,2,2,2> BK64 NST2   (eff 0: experimental, never auto-selected)
+    {128, 256, 1, true, 0.00f, 4, 8, 1},   // 8: <2,2,2,4> BK64 NST2
+    {128, 64, 2, true, 0.00f, 1, 9, 1},    // 9: <2,2,2,1> BK64 NST3
+    {320, 128, 1, false, 0.00f, 2, 10, 1},  // 10: <2,2,5,2> BK64 NST2
+    {128, 64, 2, false, 0.00f, 1, 9, 2},    // 11: cfg 9 + split-K 2
+    {128, 64, 2, false, 0.00f, 1, 9, 4},    // 12: cfg 9 + split-K 4
+    {128, 64, 2, false, 0.00f, 1, 9, 8},    // 13: cfg 9 + split-K 8
+    {128, 128, 2, false, 0.00f, 2, 7, 2},   // 14: cfg 7 + split-K 2
+    {128, 128, 2, false, 0.00f, 2, 7, 4},   // 15: cfg 7 + split-K 4
 };
 
 template <int WQ, int WP, int TQ, int TP, int BK, int NST>
@@ -412,7 +482,7 @@ int launch_cfg(IGemmArgs a, int batch, hipStream_t st) {
     const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
     int blocks = nq * np;
     a.tile_map = 0;
-    if (batch == 1) {
+    if (batch == 1 || a.splitk > 1) {
         if (np >= 16) { a.tile_map = 1; blocks = 8 * ((np + 7) / 8) * nq; }
         else if (nq >= 16) { a.tile_map = 2; blocks = 8 * ((nq + 7) / 8) * np; }
     }
@@ -476,6 +546,10 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                         if (geglu && !kCfg[c].geglu_ok) continue;
                         if (c >= 7 && ((a.C0 % 64) || (a.C1 % 64))) continue;
                         if (kCfg[c].bq > 2 * a.Q && kCfg[c].bq > 64) continue;        // grossly oversized in Q
+                        if (kCfg[c].split > 1) {                                        // split-K: few tiles, deep K only
+                            const long long tiles = (long long)((a.Q + kCfg[c].bq - 1) / kCfg[c].bq) * ((a.P + kCfg[c].bp - 1) / kCfg[c].bp);
+                            if (tiles * kCfg[c].split > 1024 || tiles > 256 || (a.K / 64) / kCfg[c].split < 8) continue;
+                        }
                         if (ladi_launch_igemm(a, batch, c, st) != 0) continue;          // warm-up (also sets function attributes)
                         (void)hipEventRecord(e0, st);
                         for (int r = 0; r < 3; ++r) (void)ladi_launch_igemm(a, batch, c, st);
@@ -510,8 +584,13 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     if (cfg < 1 || cfg > NCFG) return -7;
     if (geglu && !kCfg[cfg].geglu_ok) return -8;
     if (cfg >= 7 && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
+    const int split = kCfg[cfg].split;
+    if (split > 1) {
+        if (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel) return -9;
+        if (!ensure_ws((size_t)split * a.P * a.Q * sizeof(float), st)) return -13;
+    }
     if (a.stats) {  // fused output statistics need whole 32*TP-pixel row blocks inside one sample
-        const int px = kCfg[cfg].tp * 32;
+        const int px = (split > 1 ? 1 : kCfg[cfg].tp) * 32;
         if (geglu || batch != 1 || a.out_f32 || ((a.Ho * a.Wo) % px)) a.stats = nullptr;
         else if (stats_row_px) *stats_row_px = px;
     }
@@ -523,19 +602,31 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         rec.flops = 2.0 * (double)a.P * (double)a.Q * (double)a.K * (double)batch;
         (void)hipEventRecord(rec.e0, st);
     }
+    IGemmArgs full = a;   // epilogue parameters for the split-K reduce pass
+    int lbatch = batch;
+    if (split > 1) {
+        a.out = g_ws; a.ldo = a.Q; a.out_f32 = 1; a.bs_out = (long long)a.P * a.Q; a.splitk = split; lbatch = split;
+        a.bias = nullptr; a.rowadd = nullptr; a.act = LADI_ACT_NONE; a.out_scale = 1.f; a.res0 = nullptr; a.res1 = nullptr;
+        a.mask = nullptr; a.stats = nullptr;
+    } else a.splitk = 1;
+    const int batch_l = lbatch;
     int rc;
-    switch (cfg) {
-        case 1: rc = launch_cfg<2, 2, 2, 4, 32, 3>(a, batch, st); break;
-        case 2: rc = launch_cfg<2, 2, 5, 2, 32, 2>(a, batch, st); break;
-        case 3: rc = launch_cfg<2, 2, 2, 2, 32, 3>(a, batch, st); break;
-        case 4: rc = launch_cfg<2, 2, 2, 1, 32, 3>(a, batch, st); break;
-        case 5: rc = launch_cfg<2, 2, 1, 1, 32, 3>(a, batch, st); break;
-        case 6: rc = launch_cfg<2, 2, 4, 2, 32, 3>(a, batch, st); break;
-        case 7: rc = launch_cfg<2, 2, 2, 2, 64, 2>(a, batch, st); break;
-        case 8: rc = launch_cfg<2, 2, 2, 4, 64, 2>(a, batch, st); break;
-        case 9: rc = launch_cfg<2, 2, 2, 1, 64, 3>(a, batch, st); break;
-        case 10: rc = launch_cfg<2, 2, 5, 2, 64, 2>(a, batch, st); break;
+    switch (kCfg[cfg].base) {
+        case 1: rc = launch_cfg<2, 2, 2, 4, 32, 3>(a, batch_l, st); break;
+        case 2: rc = launch_cfg<2, 2, 5, 2, 32, 2>(a, batch_l, st); break;
+        case 3: rc = launch_cfg<2, 2, 2, 2, 32, 3>(a, batch_l, st); break;
+        case 4: rc = launch_cfg<2, 2, 2, 1, 32, 3>(a, batch_l, st); break;
+        case 5: rc = launch_cfg<2, 2, 1, 1, 32, 3>(a, batch_l, st); break;
+        case 6: rc = launch_cfg<2, 2, 4, 2, 32, 3>(a, batch_l, st); break;
+        case 7: rc = launch_cfg<2, 2, 2, 2, 64, 2>(a, batch_l, st); break;
+        case 8: rc = launch_cfg<2, 2, 2, 4, 64, 2>(a, batch_l, st); break;
+        case 9: rc = launch_cfg<2, 2, 2, 1, 64, 3>(a, batch_l, st); break;
+        case 10: rc = launch_cfg<2, 2, 5, 2, 64, 2>(a, batch_l, st); break;
         default: rc = -7;
+    }
+    if (rc == 0 && split > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((full.P + 31) / 32), (unsigned)((full.Q + 63) / 64)), dim3(256), 0, st, g_ws, split, full);
+        if (hipGetLastError() != hipSuccess) rc = -11;
     }
     if (prof) { (void)hipEventRecord(rec.e1, st); g_recs.push_back(rec); }
     return rc;

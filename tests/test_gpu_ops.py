@@ -46,6 +46,17 @@ def test_conv3x3_bias_res_temb(cin, cout, h, w, cfg):
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
 
 
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15])
+def test_conv3x3_split_k(cfg):
+    """split-K variants (fp32 partial slices + reduce pass that applies the epilogue) on a few-tile / deep-K problem"""
+    N, cin, cout, h, w = 2, 512, 192, 8, 6
+    x, wt, b = _rand((N, cin, h, w), 60), _rand((cout, cin, 3, 3), 61, 1 / math.sqrt(9 * cin)), _rand((cout,), 62, 0.1)
+    temb, res = _rand((cout,), 63), _rand((N, cout, h, w), 64)
+    ref = F.silu(F.conv2d(x, wt, b, padding=1) + temb[None, :, None, None]) + res
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cout, bias=b, rowadd=temb, act="silu", res0=U.nhwc16(res), cfg=cfg)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+
+
 def test_conv3x3_stride2_pad1_and_asym():
     N, cin, cout, h, w = 2, 64, 128, 16, 12
     x, wt, b = _rand((N, cin, h, w), 7), _rand((cout, cin, 3, 3), 8, 0.05), _rand((cout,), 9, 0.1)
