@@ -84,7 +84,13 @@ def cpu_baseline(sds, cfgs, H, W, evals, L, D):
     bounded sample of the same workload: ONE CFG UNet evaluation (n=2) + VAE encode + EMASC + VAE decode for one 512x384 image;
     images/s extrapolated as 1 / (evals * t_unet + 2 t_enc + t_emasc + t_dec)."""
     from oracle import models as M  # test infrastructure: only used as the reported CPU baseline
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:   # respect the container's cgroup CPU quota (the GPU box shows 256 logical CPUs but grants 16)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except Exception:
+        pass
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     h, w = H // 8, W // 8

@@ -22,7 +22,7 @@ constexpr float RESCALE_THR = 8.0f;  // defer the O/l rescale until the running 
 template <int V> struct SubIdx { static constexpr int value = V; };
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-__global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) h16 sK[KV_STAGE * 64];
     __shared__ __attribute__((aligned(16))) h16 sVt[64 * VT_LD];
 
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const AttnArgs a) 
     const h16* __restrict__ kp = a.k + (size_t)n * a.sk + head * 64;
     const h16* __restrict__ vp = a.v + (size_t)n * a.sv + head * 64;
 
+    const float qscale = a.scale * 1.4426950408889634f;
     // ---- Q fragments (B operand): lane = query l31, k-half hh
     h16x8 qf[4];
     {
@@ -43,6 +44,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const AttnArgs a) 
         for (int ks = 0; ks < 4; ++ks) {
             h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (qrow < a.Nq) v = *reinterpret_cast<const h16x8*>(qp + (size_t)qrow * a.ldq + ks * 16 + hh * 8);
+            // fold softmax scale * log2(e) into Q once (0.125 * log2e: the scaled value keeps full fp16 relative precision)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] * qscale);
             qf[ks] = v;
         }
     }
@@ -53,7 +57,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const AttnArgs a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
     float m_run = -1.0e30f, l_run = 0.f;
-    const float sc = a.scale * 1.4426950408889634f;
 
     // staging: every thread moves 4 x 16 B of K (rows r0 + 32 i) and one 4-key x 8-d micro-tile of V (transposed on the way)
     const int k_r0 = tid >> 3, k_c8 = tid & 7;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const AttnArgs a) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        const float sv = (key < a.Nk) ? s_acc[kb][r] * sc : -1.0e30f;
+                        const float sv = (key < a.Nk) ? s_acc[kb][r] : -1.0e30f;
                         s_acc[kb][r] = sv;
                         mt = fmaxf(mt, sv);
                     }
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const AttnArgs a) 
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { const float sv = s_acc[kb][r] * sc; s_acc[kb][r] = sv; mt = fmaxf(mt, sv); }
+                    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s_acc[kb][r]);
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             // deferred rescale (wave-uniform decision): everything still at the old max is scaled exactly once

@@ -65,31 +65,47 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const h16* __restrict__
     }
 }
 
-// one block per sample: scale_shift[n][c] = (gamma*rstd, beta - mean*gamma*rstd) for GroupNorm over the virtual concat (C0 | C1)
+// block (n, group chunk): scale_shift[n][c] = (gamma*rstd, beta - mean*gamma*rstd) for GroupNorm over the virtual concat
+// (C0 | C1).  Each block owns GPB consecutive groups (nch = GPB*gs channels); threads = (row lane, channel) so that the
+// partial rows are summed in parallel with coalesced 8-byte loads.
+constexpr int GNF_MAX_CH = 512;   // channels per block (GPB * gs)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part0, int C0, int rps0,
                                                           const float* __restrict__ part1, int C1, int rps1, int HW, int groups,
-                                                          const h16* __restrict__ gamma, const h16* __restrict__ beta, float eps,
-                                                          float* __restrict__ scale_shift) {
-    __shared__ float csum[GN_MAX_C], csq[GN_MAX_C];
-    __shared__ float gmean[64], grstd[64];
+                                                          int gpb, const h16* __restrict__ gamma, const h16* __restrict__ beta,
+                                                          float eps, float* __restrict__ scale_shift) {
+    __shared__ float rsum[256], rsq[256];
+    __shared__ float csum[GNF_MAX_CH], csq[GNF_MAX_CH];
+    __shared__ float gmean[16], grstd[16];
     const int tid = threadIdx.x, n = blockIdx.x;
     const int Ct = C0 + C1;
     const int gs = Ct / groups;
-    for (int c = tid; c < Ct; c += 256) {
-        const float* p; int C, rps, cl;
-        if (c < C0) { p = part0; C = C0; rps = rps0; cl = c; } else { p = part1; C = C1; rps = rps1; cl = c - C0; }
-        const float2* row = reinterpret_cast<const float2*>(p) + (size_t)n * rps * C + cl;
-        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-        int r = 0;
-        for (; r + 1 < rps; r += 2) {
-            const float2 a = row[(size_t)r * C], b = row[(size_t)(r + 1) * C];
-            s0 += a.x; q0 += a.y; s1 += b.x; q1 += b.y;
+    const int g0 = blockIdx.y * gpb;
+    const int ng = min(gpb, groups - g0);
+    const int cbeg = g0 * gs, nch = ng * gs;
+    const int nchp = nch < 256 ? nch : 256;     // channels handled concurrently
+    const int RL = 256 / nchp;                  // row lanes
+    const int cl = tid % nchp, rl = tid / nchp;
+    for (int cb = 0; cb < nch; cb += nchp) {
+        const int cc = cb + cl;                 // channel within this block's range
+        float s = 0.f, q = 0.f;
+        if (rl < RL && cc < nch) {
+            const int c = cbeg + cc;
+            const float* p; int C, rps, clc;
+            if (c < C0) { p = part0; C = C0; rps = rps0; clc = c; } else { p = part1; C = C1; rps = rps1; clc = c - C0; }
+            const float2* row = reinterpret_cast<const float2*>(p) + (size_t)n * rps * C + clc;
+            for (int r = rl; r < rps; r += RL) { const float2 v = row[(size_t)r * C]; s += v.x; q += v.y; }
         }
-        if (r < rps) { const float2 a = row[(size_t)r * C]; s0 += a.x; q0 += a.y; }
-        csum[c] = s0 + s1; csq[c] = q0 + q1;
+        __syncthreads();
+        if (rl < RL) { rsum[rl * nchp + cl] = s; rsq[rl * nchp + cl] = q; }
+        __syncthreads();
+        if (rl == 0 && cc < nch) {
+            float ts = 0.f, tq = 0.f;
+            for (int l = 0; l < RL; ++l) { ts += rsum[l * nchp + cl]; tq += rsq[l * nchp + cl]; }
+            csum[cc] = ts; csq[cc] = tq;
+        }
     }
     __syncthreads();
-    if (tid < groups) {
+    if (tid < ng) {
         float s = 0.f, q = 0.f;
         for (int c = tid * gs; c < (tid + 1) * gs; ++c) { s += csum[c]; q += csq[c]; }
         const float inv = 1.f / ((float)gs * (float)HW);
@@ -98,8 +114,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         gmean[tid] = mean; grstd[tid] = rsqrtf(var + eps);
     }
     __syncthreads();
-    for (int c = tid; c < Ct; c += 256) {
-        const int g = c / gs;
+    for (int cc = tid; cc < nch; cc += 256) {
+        const int c = cbeg + cc, g = cc / gs;
         const float ga = (float)gamma[c] * grstd[g];
         reinterpret_cast<float2*>(scale_shift)[(size_t)n * Ct + c] = make_float2(ga, (float)beta[c] - gmean[g] * ga);
     }
@@ -269,8 +285,12 @@ int ladi_launch_gn_finalize(const float* part0, int C0, int rps0, const float* p
                             const h16* gamma, const h16* beta, float eps, float* scale_shift, hipStream_t st) {
     const int Ct = C0 + C1;
     if (groups > 64 || (Ct % groups) || Ct > GN_MAX_C) return -1;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, st, part0, C0, rps0, part1, C1, rps1, HW, groups, gamma, beta, eps,
-                       scale_shift);
+    const int gs = Ct / groups;
+    int gpb = 4;                                   // groups per block: 8 blocks per sample for 32 groups
+    while (gpb > 1 && gpb * gs > GNF_MAX_CH) gpb >>= 1;
+    if (gpb * gs > GNF_MAX_CH || gpb > 16) return -1;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n, (groups + gpb - 1) / gpb), dim3(256), 0, st, part0, C0, rps0, part1, C1, rps1, HW,
+                       groups, gpb, gamma, beta, eps, scale_shift);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 

@@ -88,3 +88,17 @@ def psnr(a, b, peak=None):
     peak = float(b.abs().max()) if peak is None else peak
     mse = float(((a - b) ** 2).mean())
     return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)
+
+
+def cpu_quota_threads():
+    """usable host threads: min(affinity, cgroup cpu.max quota) — torch oversubscribes badly when it sees 256 logical CPUs
+    but the container is capped (the GPU box: quota 16 of 256)"""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
