@@ -44,6 +44,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--roofline-only", action="store_true",
+                   help="only the dominant-kernel measurement: CFG UNet forwards at the bench batch (the command the rocprofv3 "
+                        "summaries under profiles/ are taken from)")
+    p.add_argument("--roofline-iters", type=int, default=4)
     return p.parse_args()
 
 
@@ -77,6 +81,30 @@ def synthetic_device_inputs(B, H, W, L, D, device, seed):
         else:
             out[k] = v.to(device=device, dtype=torch.float16)
     return out
+
+
+def pmc_traffic(kernel_label):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_*.txt: separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM). None if absent."""
+    import re
+    m = re.match(r"igemm_kernel<([0-9,]+)>", kernel_label)
+    if not m:
+        return None
+    pat = "igemm_kernel<" + ", ".join(m.group(1).split(",")) + ">"
+    vals = {}
+    for tag in ("fetch", "write"):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_%s_size.txt" % tag)
+        if not os.path.exists(path):
+            return None
+        for line in open(path):
+            if pat in line:
+                f = line.split()
+                vals[tag] = float(f[-2]) * 1024.0   # avg KiB per dispatch -> bytes
+                break
+    if len(vals) != 2:
+        return None
+    return {"bytes_per_launch": round(2.0 * vals["fetch"] + vals["write"]), "fetch_bytes_x2": round(2.0 * vals["fetch"]),
+            "write_bytes": round(vals["write"]), "source": "profiles/r01_pmc_{fetch,write}_size.txt (avg over all launches of this kernel)"}
 
 
 def cpu_baseline(sds, cfgs, H, W, evals, L, D):
@@ -157,6 +185,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.roofline_only:
+        # context for the stand-alone UNet forwards; one untimed forward first (per-shape tile measurement happens there)
+        e = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]]).contiguous()
+        unet.set_context(e)
+        unet.time_forward(2 * B, H // 8, W // 8, 1)
+        out = torch.zeros((global_B, H, W, 3), dtype=torch.uint8, device=dev)
+        a.warmup, a.steps = 0, 0
     for _ in range(a.warmup):
         out = one_step()
     fence()
@@ -164,17 +199,17 @@ def main():
     for _ in range(a.steps):
         out = one_step()
     fence()
-    dt = time.time() - t0
+    dt = max(time.time() - t0, 1e-9)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     assert out.shape[0] == global_B and out.dtype == torch.uint8
-    images_per_s = global_B * a.steps / dt
+    images_per_s = global_B * a.steps / dt if a.steps else 0.0
     evals = a.inference_steps + (1 if a.scheduler == "pndm" else 0)
     lib = _lib.load()
     stage = (ctypes.c_float * 3)()
-    stage_ms = list(stage) if lib.ladi_tryon_stage_ms(pipe._tryon, stage) == 0 else None
+    stage_ms = list(stage) if (pipe._tryon and lib.ladi_tryon_stage_ms(pipe._tryon, stage) == 0) else None
     if stage_ms is not None:
         stage_ms = [float(stage[i]) for i in range(3)]
 
@@ -184,9 +219,9 @@ def main():
         # Per-launch HIP events on the launch stream around every igemm launch of CFG UNet forwards at the bench batch.
         n = 2 * B
         h, w = H // 8, W // 8
-        whole_ms = unet.time_forward(n, h, w, 2)
+        whole_ms = unet.time_forward(n, h, w, a.roofline_iters)
         lib.ladi_profile_igemm_enable(1)
-        unet.time_forward(n, h, w, 1)   # 1 warm-up + 1 timed forward, both recorded
+        unet.time_forward(n, h, w, a.roofline_iters)   # 1 warm-up + roofline_iters timed forwards, all recorded
         lib.ladi_profile_igemm_enable(0)
         prof = (ctypes.c_double * 51)()
         lib.ladi_profile_igemm_collect(prof, 51)
@@ -204,7 +239,7 @@ def main():
         if dom:
             ach = per[dom]["tflops"]
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4),
-                        "traffic": None, "kernel": per[dom]["kernel"], "avg_launch_ms": round(per[dom]["avg_ms"], 5),
+                        "traffic": pmc_traffic(per[dom]["kernel"]), "kernel": per[dom]["kernel"], "avg_launch_ms": round(per[dom]["avg_ms"], 5),
                         "flop_per_launch": per[dom]["flop_per_launch"], "launches_profiled": per[dom]["launches"],
                         "igemm_all_tflops": round(prof[1] / prof[0] / 1e9, 2) if prof[0] > 0 else None,
                         "per_config": {per[k]["kernel"]: {"tflops": round(per[k]["tflops"], 1), "launches": per[k]["launches"],
@@ -221,7 +256,7 @@ def main():
     if rank == 0:
         line = {
             "metric": "try-on images/sec @512x384, 50 %s steps" % a.scheduler.upper(), "value": round(images_per_s, 4), "unit": "images/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1000.0, 2), "higher_is_better": True,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1000.0, 2) if a.steps else None, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: VITON-HD-paired-like, batch %d per GPU, %d %s steps (%d UNet evals, CFG 7.5), %dx%d, "
                                    "EMASC skips on, fp16 storage / fp32 accumulate, %s-size random-init checkpoint" % (B, a.inference_steps, a.scheduler.upper(), evals, H, W, a.size),

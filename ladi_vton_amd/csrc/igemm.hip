@@ -511,6 +511,28 @@ struct TuneHash {
 };
 bool g_autotune = true;
 std::unordered_map<TuneKey, int, TuneHash> g_tuned;
+// optional persistence of the measured choices across processes (LADI_TUNE_CACHE=<file>): one line per problem shape
+bool g_cache_loaded = false;
+void tune_cache_load() {
+    if (g_cache_loaded) return;
+    g_cache_loaded = true;
+    const char* path = getenv("LADI_TUNE_CACHE");
+    if (!path) return;
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    TuneKey k; int cfg;
+    while (fscanf(f, "%d %d %d %d %d %d %d %d %d", &k.P, &k.Q, &k.K, &k.C0, &k.C1, &k.Wo, &k.flags, &k.batch, &cfg) == 9)
+        if (cfg >= 1 && cfg <= 64) g_tuned[k] = cfg;
+    fclose(f);
+}
+void tune_cache_append(const TuneKey& k, int cfg) {
+    const char* path = getenv("LADI_TUNE_CACHE");
+    if (!path) return;
+    FILE* f = fopen(path, "a");
+    if (!f) return;
+    fprintf(f, "%d %d %d %d %d %d %d %d %d\n", k.P, k.Q, k.K, k.C0, k.C1, k.Wo, k.flags, k.batch, cfg);
+    fclose(f);
+}
 
 }  // namespace
 
@@ -531,6 +553,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     //      Re-running a launch is idempotent (outputs never alias inputs in this library).
     TuneKey key{a.P, a.Q, a.K, a.C0, a.C1, a.Wo, (a.ksize << 8) | (a.stride << 4) | (a.ups << 2) | (geglu ? 1 : 0), batch};
     if (cfg == 0 && g_autotune) {
+        tune_cache_load();
         auto it = g_tuned.find(key);
         if (it != g_tuned.end()) cfg = it->second;
         else {
@@ -559,7 +582,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best_cfg = c; }
                     }
                     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-                    if (best_cfg) { g_tuned[key] = best_cfg; cfg = best_cfg; }
+                    if (best_cfg) { g_tuned[key] = best_cfg; cfg = best_cfg; tune_cache_append(key, best_cfg); }
                 }
                 g_autotune = was;
             }
