@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmArgs a) {
     constexpr int RQ = BQ / RPP, RP = BP / RPP;
     constexpr int STAGE = (BQ + BP) * BK;  // halves per stage
     constexpr int NKK = BK / 16;
-    static_assert(NST == 2 || NST == 3, "ring depth");
+    static_assert(NST >= 2 && NST <= 4, "ring depth");
     static_assert(BQ % RPP == 0 && BP % RPP == 0, "tile rows must be a multiple of the rows per pass");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     h16* smem = reinterpret_cast<h16*>(smem_raw);
@@ -178,8 +178,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         // my part of stage kt has landed (later stages may stay in flight), then rendezvous: every wave's part of stage kt is
         // visible and every wave has finished reading the ring slot that is refilled next
-        if (NST == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(L) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            const int later = min(NST - 2, nk - 1 - kt);   // stages issued after stage kt that may stay in flight
+            if (NST >= 4 && later >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * L) : "memory");
+            else if (NST >= 3 && later >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(L) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         if (kt + NST - 1 < nk) issue((kt + NST - 1) % NST);
         const h16* sW = smem + (kt % NST) * STAGE;
         const h16* sX = sW + BQ * BK;
@@ -448,7 +452,7 @@ bool ensure_ws(size_t bytes, hipStream_t st) {
 
 struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; int base; int split; };
 // cfg 1..6 (0 = auto)
-constexpr int NCFG = 15;
+constexpr int NCFG = 18;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1},
     {128, 256, 2, true, 0.80f, 4, 1, 1},   // 1: <2,2,2,4> BK32 NST3
@@ -466,6 +470,9 @@ const CfgInfo kCfg[NCFG + 1] = {
     {128, 64, 2, false, 0.00f, 1, 9, 8},    // 13: cfg 9 + split-K 8
     {128, 128, 2, false, 0.00f, 2, 7, 2},   // 14: cfg 7 + split-K 2
     {128, 128, 2, false, 0.00f, 2, 7, 4},   // 15: cfg 7 + split-K 4
+    {64, 64, 5, false, 0.00f, 1, 16, 1},    // 16: <2,2,1,1> BK32 NST4 (deeper prefetch for shallow-K, latency-bound GEMMs)
+    {128, 64, 3, true, 0.00f, 1, 17, 1},    // 17: <2,2,2,1> BK32 NST4
+    {128, 128, 2, true, 0.00f, 2, 18, 1},   // 18: <2,2,2,2> BK32 NST4
 };
 
 template <int WQ, int WP, int TQ, int TP, int BK, int NST>
@@ -567,7 +574,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                     for (int c = 1; c <= NCFG; ++c) {
                         if (kCfg[c].blocks_per_cu < 2) continue;                       // 1-block/CU shapes never won
                         if (geglu && !kCfg[c].geglu_ok) continue;
-                        if (c >= 7 && ((a.C0 % 64) || (a.C1 % 64))) continue;
+                        if (c >= 7 && c <= 15 && ((a.C0 % 64) || (a.C1 % 64))) continue;
                         if (kCfg[c].bq > 2 * a.Q && kCfg[c].bq > 64) continue;        // grossly oversized in Q
                         if (kCfg[c].split > 1) {                                        // split-K: few tiles, deep K only
                             const long long tiles = (long long)((a.Q + kCfg[c].bq - 1) / kCfg[c].bq) * ((a.P + kCfg[c].bp - 1) / kCfg[c].bp);
@@ -606,7 +613,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     }
     if (cfg < 1 || cfg > NCFG) return -7;
     if (geglu && !kCfg[cfg].geglu_ok) return -8;
-    if (cfg >= 7 && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
+    if (cfg >= 7 && cfg <= 15 && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
     const int split = kCfg[cfg].split;
     if (split > 1) {
         if (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel) return -9;
@@ -645,6 +652,9 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         case 8: rc = launch_cfg<2, 2, 2, 4, 64, 2>(a, batch_l, st); break;
         case 9: rc = launch_cfg<2, 2, 2, 1, 64, 3>(a, batch_l, st); break;
         case 10: rc = launch_cfg<2, 2, 5, 2, 64, 2>(a, batch_l, st); break;
+        case 16: rc = launch_cfg<2, 2, 1, 1, 32, 4>(a, batch_l, st); break;
+        case 17: rc = launch_cfg<2, 2, 2, 1, 32, 4>(a, batch_l, st); break;
+        case 18: rc = launch_cfg<2, 2, 2, 2, 32, 4>(a, batch_l, st); break;
         default: rc = -7;
     }
     if (rc == 0 && split > 1) {

@@ -175,49 +175,69 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ s
     }
 }
 
-// one wave per row; C % 8 == 0, C <= 4096
+// LayerNorm: each wave normalises R consecutive rows with all of their 16-byte loads in flight at once (rows are only 640 B - 2.5 KB,
+// so one row per wave leaves the memory system idle); statistics two-pass in registers. C % 8 == 0, C <= 64*8*MAXO.
+template <int R, int MAXO>
 __global__ __launch_bounds__(256) void layernorm_kernel(const h16* __restrict__ x, int ldx, const h16* __restrict__ gamma,
                                                         const h16* __restrict__ beta, float eps, int rows, int C,
                                                         h16* __restrict__ out, int ldo) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= rows) return;
+    const int row0 = (blockIdx.x * 4 + wave) * R;
+    if (row0 >= rows) return;
     const int octs = C >> 3;
-    constexpr int MAXO = 8;  // up to 8 octets per lane -> C <= 4096
-    h16x8 v[MAXO];
-    float s = 0.f;
+    h16x8 v[R][MAXO];
+    float s[R];
 #pragma unroll
-    for (int i = 0; i < MAXO; ++i) {
-        const int oc = lane + 64 * i;
-        if (oc < octs) {
-            v[i] = *reinterpret_cast<const h16x8*>(x + (size_t)row * ldx + oc * 8);
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+        const bool rv = row0 + r < rows;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+        for (int i = 0; i < MAXO; ++i) {
+            const int oc = lane + 64 * i;
+            h16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (rv && oc < octs) t = *reinterpret_cast<const h16x8*>(x + (size_t)(row0 + r) * ldx + oc * 8);
+            v[r][i] = t;
         }
     }
-    s = wave_sum(s);
-    const float mean = s / (float)C;
-    float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXO; ++i) {
-        const int oc = lane + 64 * i;
-        if (oc < octs) {
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { float d = (float)v[i][e] - mean; ss += d * d; }
-        }
+        for (int i = 0; i < MAXO; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[r] += (float)v[r][i][e];
+        s[r] = wave_sum(s[r]);
     }
-    ss = wave_sum(ss);
-    const float rstd = rsqrtf(ss / (float)C + eps);
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mean[r] = s[r] / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXO; ++i) {
+            const int oc = lane + 64 * i;
+            if (oc < octs) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)v[r][i][e] - mean[r]; ss += d * d; }
+            }
+        }
+        ss = wave_sum(ss);
+        rstd[r] = rsqrtf(ss / (float)C + eps);
+    }
 #pragma unroll
     for (int i = 0; i < MAXO; ++i) {
         const int oc = lane + 64 * i;
         if (oc < octs) {
             const h16x8 g = *reinterpret_cast<const h16x8*>(gamma + oc * 8);
             const h16x8 b = *reinterpret_cast<const h16x8*>(beta + oc * 8);
-            h16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)v[i][e] - mean) * rstd * (float)g[e] + (float)b[e]);
-            *reinterpret_cast<h16x8*>(out + (size_t)row * ldo + oc * 8) = o;
+            for (int r = 0; r < R; ++r) {
+                if (row0 + r < rows) {
+                    h16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)v[r][i][e] - mean[r]) * rstd[r] * (float)g[e] + (float)b[e]);
+                    *reinterpret_cast<h16x8*>(out + (size_t)(row0 + r) * ldo + oc * 8) = o;
+                }
+            }
         }
     }
 }
@@ -307,7 +327,10 @@ int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int 
 int ladi_launch_layernorm(const h16* x, int ldx, const h16* gamma, const h16* beta, float eps, int rows, int C, h16* out,
                           int ldo, hipStream_t st) {
     if ((C & 7) || C > 4096 || (ldx & 7) || (ldo & 7)) return -1;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, gamma, beta, eps, rows, C, out, ldo);
+    const int octs = C >> 3;
+    if (octs <= 64) hipLaunchKernelGGL((layernorm_kernel<4, 1>), dim3((rows + 15) / 16), dim3(256), 0, st, x, ldx, gamma, beta, eps, rows, C, out, ldo);
+    else if (octs <= 192) hipLaunchKernelGGL((layernorm_kernel<4, 3>), dim3((rows + 15) / 16), dim3(256), 0, st, x, ldx, gamma, beta, eps, rows, C, out, ldo);
+    else hipLaunchKernelGGL((layernorm_kernel<1, 8>), dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, gamma, beta, eps, rows, C, out, ldo);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 

@@ -21,7 +21,7 @@ def _rand(shape, seed, scale=1.0):
 
 
 # --------------------------------------------------------------------------------------------------------------- igemm
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 16, 17, 18])
 def test_mfma_layout_asymmetric(cfg):
     """transpose-detecting check of the MFMA fragment / accumulator mapping: 1x1 'conv' with an asymmetric weight."""
     N, H, W, C, Q = 1, 16, 24, 64, 192
