@@ -157,12 +157,16 @@ def main():
     ecfg = C.emasc_for_vae(vcfg)
     cfgs = dict(unet=ucfg, vae=vcfg, emasc=ecfg)
     t_build = time.time()
-    sds = dict(unet=C.synth_state_dict(C.unet_shapes(ucfg), "unet."), vae=C.synth_state_dict(C.vae_shapes(vcfg), "vae."),
-               emasc=C.synth_state_dict(C.emasc_shapes(ecfg), "emasc."))
-    unet, vae, emasc = L.NativeUNet(ucfg, sds["unet"]), L.NativeVAE(vcfg, sds["vae"]), L.NativeEMASC(ecfg, sds["emasc"])
-    want_cpu = (rank == 0 and world == 1 and not a.no_cpu_baseline)
-    if not want_cpu:
+    want_cpu = (rank == 0 and world == 1 and not a.no_cpu_baseline and not a.roofline_only)
+    if want_cpu:   # the CPU baseline needs the fp32 checkpoint on the host; otherwise stream it tensor by tensor
+        sds = dict(unet=C.synth_state_dict(C.unet_shapes(ucfg), "unet."), vae=C.synth_state_dict(C.vae_shapes(vcfg), "vae."),
+                   emasc=C.synth_state_dict(C.emasc_shapes(ecfg), "emasc."))
+        unet, vae, emasc = L.NativeUNet(ucfg, sds["unet"]), L.NativeVAE(vcfg, sds["vae"]), L.NativeEMASC(ecfg, sds["emasc"])
+    else:
         sds = None
+        unet = L.NativeUNet(ucfg, C.synth_items(C.unet_shapes(ucfg), "unet."))
+        vae = L.NativeVAE(vcfg, C.synth_items(C.vae_shapes(vcfg), "vae."))
+        emasc = L.NativeEMASC(ecfg, C.synth_items(C.emasc_shapes(ecfg), "emasc."))
     sch = L.DDIMScheduler() if a.scheduler == "ddim" else L.PNDMScheduler()
     pipe = L.StableDiffusionTryOnePipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, scheduler=sch, emasc=emasc,
                                            emasc_int_layers=[1, 2, 3, 4, 5])
@@ -223,15 +227,18 @@ def main():
         lib.ladi_profile_igemm_enable(1)
         unet.time_forward(n, h, w, a.roofline_iters)   # 1 warm-up + roofline_iters timed forwards, all recorded
         lib.ladi_profile_igemm_enable(0)
-        prof = (ctypes.c_double * 51)()
-        lib.ladi_profile_igemm_collect(prof, 51)
+        prof = (ctypes.c_double * 72)()
+        lib.ladi_profile_igemm_collect(prof, 72)
         names = {1: "igemm_kernel<2,2,2,4,32,3> (Q128xP256)", 2: "igemm_kernel<2,2,5,2,32,2> (Q320xP128)", 3: "igemm_kernel<2,2,2,2,32,3> (Q128xP128)",
                  4: "igemm_kernel<2,2,2,1,32,3> (Q128xP64)", 5: "igemm_kernel<2,2,1,1,32,3> (Q64xP64)", 6: "igemm_kernel<2,2,4,2,32,3> (Q256xP128)"}
         per = {}
         names.update({7: "igemm_kernel<2,2,2,2,64,2> (Q128xP128 BK64)", 8: "igemm_kernel<2,2,2,4,64,2> (Q128xP256 BK64)", 9: "igemm_kernel<2,2,2,1,64,3> (Q128xP64 BK64)",
                       10: "igemm_kernel<2,2,5,2,64,2> (Q320xP128 BK64)"})
         names.update({11: "cfg9 + split-K 2", 12: "cfg9 + split-K 4", 13: "cfg9 + split-K 8", 14: "cfg7 + split-K 2", 15: "cfg7 + split-K 4"})
-        for c_ in range(1, 16):
+        names.update({16: "igemm_kernel<2,2,1,1,32,4> (Q64xP64 NST4)", 17: "igemm_kernel<2,2,2,1,32,4> (Q128xP64 NST4)", 18: "igemm_kernel<2,2,2,2,32,4> (Q128xP128 NST4)",
+                      19: "igemm_kernel<2,4,2,2,32,3> (Q128xP256, 8 waves)", 20: "igemm_kernel<4,2,2,2,32,3> (Q256xP128, 8 waves)",
+                      21: "igemm_kernel<2,4,4,2,32,3> (Q256xP256, 8 waves)", 22: "igemm_kernel<2,4,5,2,64,2> (Q320xP256, 8 waves)"})
+        for c_ in range(1, 23):
             ms, fl, cnt = prof[c_ * 3], prof[c_ * 3 + 1], prof[c_ * 3 + 2]
             if cnt > 0:
                 per[c_] = dict(kernel=names[c_], launches=int(cnt), avg_ms=ms / cnt, flop_per_launch=fl / cnt, tflops=fl / ms / 1e9)

@@ -212,6 +212,14 @@ def synth_tensor(key, shape, scope=""):
     return u * 0.1                            # biases
 
 
+def synth_items(shapes, scope="", fp16_round=True):
+    """generator of (key, tensor) pairs of the synthetic checkpoint: lets a loader stream 866 M parameters without holding the
+    whole fp32 state_dict in host memory (one per rank under torchrun)"""
+    for k, s in shapes.items():
+        t = synth_tensor(k, s, scope)
+        yield k, (t.half().float() if fp16_round else t)
+
+
 def synth_state_dict(shapes, scope="", fp16_round=True):
     """fp32 tensors whose values are exactly representable in fp16 (so weight quantisation is not counted as error)."""
     sd = OrderedDict()

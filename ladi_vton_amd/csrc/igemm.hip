@@ -46,10 +46,11 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 }
 
 template <int WQ, int WP, int TQ, int TP, int BK, int NST>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmArgs a) {
+__global__ __launch_bounds__(64 * WQ * WP, 2) void igemm_kernel(const IGemmArgs a) {
     constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
     constexpr int CPR = BK / 8;          // 16-byte chunks per LDS row
-    constexpr int RPP = 256 / CPR;       // tile rows covered by one pass of the 256 threads
+    constexpr int NT = 64 * WQ * WP;      // threads per workgroup (4 or 8 waves)
+    constexpr int RPP = NT / CPR;        // tile rows covered by one pass of the workgroup
     constexpr int RQ = BQ / RPP, RP = BP / RPP;
     constexpr int STAGE = (BQ + BP) * BK;  // halves per stage
     constexpr int NKK = BK / 16;
@@ -452,7 +453,7 @@ bool ensure_ws(size_t bytes, hipStream_t st) {
 
 struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; int base; int split; };
 // cfg 1..6 (0 = auto)
-constexpr int NCFG = 18;
+constexpr int NCFG = 22;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1},
     {128, 256, 2, true, 0.80f, 4, 1, 1},   // 1: <2,2,2,4> BK32 NST3
@@ -473,6 +474,10 @@ const CfgInfo kCfg[NCFG + 1] = {
     {64, 64, 5, false, 0.00f, 1, 16, 1},    // 16: <2,2,1,1> BK32 NST4 (deeper prefetch for shallow-K, latency-bound GEMMs)
     {128, 64, 3, true, 0.00f, 1, 17, 1},    // 17: <2,2,2,1> BK32 NST4
     {128, 128, 2, true, 0.00f, 2, 18, 1},   // 18: <2,2,2,2> BK32 NST4
+    {128, 256, 2, true, 0.00f, 2, 19, 1},   // 19: <2,4,2,2> BK32 NST3   8 waves (512 threads)
+    {256, 128, 2, true, 0.00f, 2, 20, 1},   // 20: <4,2,2,2> BK32 NST3   8 waves
+    {256, 256, 2, true, 0.00f, 2, 21, 1},   // 21: <2,4,4,2> BK32 NST3   8 waves, 96 KB LDS (1 workgroup / CU; listed as 2 so the tuner tries it)
+    {320, 256, 2, false, 0.00f, 2, 22, 1},  // 22: <2,4,5,2> BK64 NST2   8 waves, 144 KB LDS
 };
 
 template <int WQ, int WP, int TQ, int TP, int BK, int NST>
@@ -494,7 +499,7 @@ int launch_cfg(IGemmArgs a, int batch, hipStream_t st) {
         else if (nq >= 16) { a.tile_map = 2; blocks = 8 * ((nq + 7) / 8) * np; }
     }
     dim3 grid((unsigned)blocks, 1, (unsigned)batch);
-    hipLaunchKernelGGL(kfn, grid, dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL(kfn, grid, dim3(64 * WQ * WP), SMEM, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 
@@ -574,7 +579,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                     for (int c = 1; c <= NCFG; ++c) {
                         if (kCfg[c].blocks_per_cu < 2) continue;                       // 1-block/CU shapes never won
                         if (geglu && !kCfg[c].geglu_ok) continue;
-                        if (c >= 7 && c <= 15 && ((a.C0 % 64) || (a.C1 % 64))) continue;
+                        if (((c >= 7 && c <= 15) || c == 22) && ((a.C0 % 64) || (a.C1 % 64))) continue;
                         if (kCfg[c].bq > 2 * a.Q && kCfg[c].bq > 64) continue;        // grossly oversized in Q
                         if (kCfg[c].split > 1) {                                        // split-K: few tiles, deep K only
                             const long long tiles = (long long)((a.Q + kCfg[c].bq - 1) / kCfg[c].bq) * ((a.P + kCfg[c].bp - 1) / kCfg[c].bp);
@@ -613,7 +618,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     }
     if (cfg < 1 || cfg > NCFG) return -7;
     if (geglu && !kCfg[cfg].geglu_ok) return -8;
-    if (cfg >= 7 && cfg <= 15 && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
+    if (((cfg >= 7 && cfg <= 15) || cfg == 22) && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
     const int split = kCfg[cfg].split;
     if (split > 1) {
         if (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel) return -9;
@@ -655,6 +660,10 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         case 16: rc = launch_cfg<2, 2, 1, 1, 32, 4>(a, batch_l, st); break;
         case 17: rc = launch_cfg<2, 2, 2, 1, 32, 4>(a, batch_l, st); break;
         case 18: rc = launch_cfg<2, 2, 2, 2, 32, 4>(a, batch_l, st); break;
+        case 19: rc = launch_cfg<2, 4, 2, 2, 32, 3>(a, batch_l, st); break;
+        case 20: rc = launch_cfg<4, 2, 2, 2, 32, 3>(a, batch_l, st); break;
+        case 21: rc = launch_cfg<2, 4, 4, 2, 32, 3>(a, batch_l, st); break;
+        case 22: rc = launch_cfg<2, 4, 5, 2, 64, 2>(a, batch_l, st); break;
         default: rc = -7;
     }
     if (rc == 0 && split > 1) {

@@ -133,7 +133,7 @@ struct UNet {
     int temb_total = 0;
     // context (cross-attention K/V) cache
     int ctx_n = 0, ctx_L = 0, ctx_cap_n = 0;
-    DevPool ctx_pool;
+    std::unique_ptr<DevPool> ctx_pool;
     // time-embedding table
     float* temb_table = nullptr; int temb_rows_cap = 0; int temb_rows = 0;
     // own arena for the stand-alone forward entry

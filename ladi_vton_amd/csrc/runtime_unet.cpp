@@ -97,9 +97,8 @@ int UNet::set_context(const h16* ehs, int n, int L, hipStream_t st) {
     all.push_back(&mid_xf);
     for (auto& x : up_xf) all.push_back(&x);
     if (n * L > ctx_cap_n) {
-        ctx_pool.~DevPool();
-        new (&ctx_pool) DevPool();
-        for (auto* x : all) x->kv_cache = reinterpret_cast<h16*>(ctx_pool.alloc((size_t)n * L * 2 * x->C * sizeof(h16)));
+        ctx_pool.reset(new DevPool());   // frees the previous (smaller) K/V cache
+        for (auto* x : all) x->kv_cache = reinterpret_cast<h16*>(ctx_pool->alloc((size_t)n * L * 2 * x->C * sizeof(h16)));
         ctx_cap_n = n * L;
     }
     ctx_n = n; ctx_L = L;

@@ -26,7 +26,8 @@ class _Weights:
         self.h = self.lib.ladi_weights_create()
         if not self.h:
             raise NativeError("ladi_weights_create failed")
-        for k, v in state_dict.items():
+        items = state_dict.items() if hasattr(state_dict, "items") else state_dict   # dict or iterator of (key, tensor) pairs
+        for k, v in items:
             t = v.detach().to("cpu")
             if t.dtype not in (torch.float32, torch.float16):
                 t = t.float()

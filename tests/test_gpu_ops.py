@@ -21,7 +21,18 @@ def _rand(shape, seed, scale=1.0):
 
 
 # --------------------------------------------------------------------------------------------------------------- igemm
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 16, 17, 18])
+@pytest.mark.parametrize("cfg", [19, 20, 21, 22])
+def test_conv3x3_eight_wave_tiles(cfg):
+    """8-wave (512-thread) workgroup tile shapes, ragged pixel count, residual + statistics-free epilogue"""
+    N, cin, cout, h, w = 3, 128, 320, 20, 13
+    x, wt, b = _rand((N, cin, h, w), 70), _rand((cout, cin, 3, 3), 71, 1 / math.sqrt(9 * cin)), _rand((cout,), 72, 0.1)
+    res = _rand((N, cout, h, w), 73)
+    ref = F.conv2d(x, wt, b, padding=1) + res
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cout, bias=b, res0=U.nhwc16(res), cfg=cfg)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 16, 17, 18, 19, 20, 21, 22])
 def test_mfma_layout_asymmetric(cfg):
     """transpose-detecting check of the MFMA fragment / accumulator mapping: 1x1 'conv' with an asymmetric weight."""
     N, H, W, C, Q = 1, 16, 24, 64, 192

@@ -27,6 +27,8 @@ SHAPES = [
     ("unet lin 640->5120 T768", 768, 1, 640, 5120, 1),
     ("unet lin 1280->10240 T192", 192, 1, 1280, 10240, 1),
     ("unet lin 5120->1280 T192", 192, 1, 5120, 1280, 1),
+    ("unet lin 1280->1280 T192", 192, 1, 1280, 1280, 1),
+    ("unet lin 640->640 T768", 768, 1, 640, 640, 1),
 ]
 VAE_SHAPES = [
     ("vae conv3 128->128 @512x384", 512, 384, 128, 128, 3),
@@ -69,11 +71,14 @@ def main():
     ap.add_argument("--n", type=int, default=16)
     ap.add_argument("--vae-n", type=int, default=2)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
     a = ap.parse_args()
     cfgs = [int(c) for c in a.cfgs.split(",")]
     print("%-40s " % "shape" + " ".join("cfg%-2d TF/s (ms)   " % c for c in cfgs))
     for shapes, n in ((SHAPES, a.n), (VAE_SHAPES, a.vae_n)):
         for (name, H, W, cin, cout, k) in shapes:
+            if a.only and a.only not in name:
+                continue
             cells = []
             for c in cfgs:
                 r = run(name, n, H, W, cin, cout, k, c, a.iters)
