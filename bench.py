@@ -262,7 +262,7 @@ def main():
             cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0:
         line = {
-            "metric": "try-on images/sec @512x384, 50 %s steps" % a.scheduler.upper(), "value": round(images_per_s, 4), "unit": "images/s",
+            "metric": "try-on images/sec @%dx%d, %d %s steps" % (H, W, a.inference_steps, a.scheduler.upper()), "value": round(images_per_s, 4), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1000.0, 2) if a.steps else None, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: VITON-HD-paired-like, batch %d per GPU, %d %s steps (%d UNet evals, CFG 7.5), %dx%d, "

@@ -1,17 +1,21 @@
 // Fused (flash-style) attention for head_dim = 64 on gfx950 MFMA, plus a single-query VALU kernel.
 //
 // flash_attn64: used by all 16 self- and 16 cross-attention layers of the UNet.
-//   Block = 4 waves = 128 queries of one (sample, head); each wave owns 32 queries.
+//   Block = 4 waves; each wave owns QB x 32 queries of one (sample, head) (QB = 2 for the long self-attention layers: every
+//   K / V^T fragment read from LDS then feeds two MFMAs).
 //   Swapped product S^T = K Q^T (A = K tile from LDS, B = Q held in registers) so that each lane owns ONE
 //   query column: the online-softmax max / sum / rescale are lane-local (one cross-half shuffle), and the
 //   exponentiated P registers are directly the B operand of O^T += V^T P^T (k index permutation
 //   key = 4*half + (j&3) + 8*(j>>2) is applied to the V^T A-operand reads instead of moving P).
-//   K stage: [128 keys][64 d] fp16, 16-byte chunks XOR-swizzled; the V stage is transposed while staging
-//   (4 keys x 8 d micro-tiles per thread, 8-byte LDS writes) into V^T[d][128 keys + 4 pad]; two 64-key compute
-//   sub-tiles per barrier pair.  Softmax: raw v_exp_f32, masking only on the ragged last sub-tile, and the O/l
-//   rescale deferred until the running max grows by more than 2^8 (wave-uniform decision; P <= 256 fits fp16).
+//   K stage: [128 keys][64 d] fp16, 16-byte chunks XOR-swizzled, double-buffered and filled by LDS-DMA one stage ahead
+//   (no staging registers); the V stage is transposed while staging (4 keys x 8 d micro-tiles per thread, 8-byte LDS
+//   writes) into V^T[d][128 keys + 4 pad]; two 64-key compute sub-tiles per barrier pair.
+//   Softmax: the running reference m_run is folded into the S accumulator init (the MFMA delivers s - m_run, no
+//   per-element subtract), raw v_exp_f32, masking only on the ragged last sub-tile, and the O/l rescale deferred
+//   until the tile maximum exceeds the reference by more than 2^8 (wave-uniform decision; P <= 256 fits fp16).
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -19,17 +23,21 @@ constexpr int KV_STAGE = 128;        // keys staged per barrier pair (two 64-key
 constexpr int VT_LD = KV_STAGE + 4;  // halves per V^T row (8-byte aligned rows, conflict-free 8-byte column reads)
 constexpr float RESCALE_THR = 8.0f;  // defer the O/l rescale until the running max grows by more than 2^8 (P <= 256 fits fp16)
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int V> struct SubIdx { static constexpr int value = V; };
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-__global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) h16 sK[KV_STAGE * 64];
+// QB = 32-query blocks per wave: every K / V^T fragment read from LDS feeds QB MFMAs (QB = 2 halves the LDS read traffic per
+// MFMA for the long self-attention layers; QB = 1 keeps more blocks in flight for short sequences)
+template <int QB>
+__global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) h16 sKbuf[2 * KV_STAGE * 64];   // double buffer: filled by LDS-DMA one stage ahead
     __shared__ __attribute__((aligned(16))) h16 sVt[64 * VT_LD];
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, hh = lane >> 5;
     const int head = blockIdx.y, n = blockIdx.z;
-    const int qbase = blockIdx.x * 128 + wave * 32;
+    const int qbase = blockIdx.x * (128 * QB) + wave * (32 * QB);
 
     const h16* __restrict__ qp = a.q + (size_t)n * a.sq + head * 64;
     const h16* __restrict__ kp = a.k + (size_t)n * a.sk + head * 64;
@@ -37,9 +45,10 @@ __global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const AttnArgs a) 
 
     const float qscale = a.scale * 1.4426950408889634f;
     // ---- Q fragments (B operand): lane = query l31, k-half hh
-    h16x8 qf[4];
-    {
-        const int qrow = qbase + l31;
+    h16x8 qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = qbase + qb * 32 + l31;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -47,27 +56,37 @@ __global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const AttnArgs a) 
             // fold softmax scale * log2(e) into Q once (0.125 * log2e: the scaled value keeps full fp16 relative precision)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] * qscale);
-            qf[ks] = v;
+            qf[qb][ks] = v;
         }
     }
 
-    f32x16 o_acc[2];
+    f32x16 o_acc[QB][2];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = 0.f;   // reference offset of the exponent; set by the first sub-tile
+        l_run[qb] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
-    float m_run = -1.0e30f, l_run = 0.f;
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[qb][d][r] = 0.f;
+    }
 
-    // staging: every thread moves 4 x 16 B of K (rows r0 + 32 i) and one 4-key x 8-d micro-tile of V (transposed on the way)
+    // staging.  K: 4 x 16 B per thread by LDS-DMA (buffer_load ... lds) straight into the next sK buffer; the LDS image of a DMA
+    // is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk (same scheme as igemm.hip).  V: one 4-key x 8-d
+    // micro-tile per thread through registers (transposed on the way into sVt).
     const int k_r0 = tid >> 3, k_c8 = tid & 7;
+    const int k_clog = k_c8 ^ ((k_r0 >> 1) & 7);     // rows k_r0 + 32 i share (row >> 1) & 7
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(kp), 0, 0x7FFFFFFF, 0x00020000);
     const int v_quad = tid & 31, v_oct = tid >> 5;   // keys 4*quad.., d = 8*oct..
-    uint4 kst0, kst1, kst2, kst3, vst0, vst1, vst2, vst3;   // named scalars: arrays captured by lambdas were demoted to scratch
+    uint4 vst0, vst1, vst2, vst3;   // named scalars: arrays captured by lambdas were demoted to scratch
 
-#define FA_KLOAD(dst, i)                                                                                   \
+#define FA_KDMA(buf, i)                                                                                    \
     {                                                                                                      \
         const int key = key0_ + k_r0 + 32 * (i);                                                           \
         const int kc = key < a.Nk ? key : a.Nk - 1; /* clamp (masked later) instead of branching */        \
-        dst = *reinterpret_cast<const uint4*>(kp + (size_t)kc * a.ldk + k_c8 * 8);                         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(reinterpret_cast<char*>(sKbuf) + (buf) * (KV_STAGE * 128) + (i) * 4096 + wave * 1024), \
+                                                 16, (unsigned)((kc * a.ldk + k_clog * 8) * 2), 0, 0, 0);  \
     }
 #define FA_VLOAD(dst, i)                                                                                   \
     {                                                                                                      \
@@ -75,10 +94,10 @@ __global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const AttnArgs a) 
         dst = make_uint4(0, 0, 0, 0); /* V rows past Nk must be exact zeros (0 * garbage could be NaN) */  \
         if (key < a.Nk) dst = *reinterpret_cast<const uint4*>(vp + (size_t)key * a.ldv + v_oct * 8);       \
     }
-#define FA_GLOAD(k0v)                                                                                      \
+#define FA_GLOAD(k0v, buf)                                                                                 \
     {                                                                                                      \
         const int key0_ = (k0v);                                                                           \
-        FA_KLOAD(kst0, 0) FA_KLOAD(kst1, 1) FA_KLOAD(kst2, 2) FA_KLOAD(kst3, 3)                            \
+        FA_KDMA(buf, 0) FA_KDMA(buf, 1) FA_KDMA(buf, 2) FA_KDMA(buf, 3)                                    \
         FA_VLOAD(vst0, 0) FA_VLOAD(vst1, 1) FA_VLOAD(vst2, 2) FA_VLOAD(vst3, 3)                            \
     }
 #define FA_VROW(e, comp, odd)                                                                              \
@@ -90,79 +109,93 @@ __global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const AttnArgs a) 
     }
 #define FA_LSTORE()                                                                                        \
     {                                                                                                      \
-        *reinterpret_cast<uint4*>(sK + kswz(k_r0, k_c8)) = kst0;                                           \
-        *reinterpret_cast<uint4*>(sK + kswz(k_r0 + 32, k_c8)) = kst1;                                      \
-        *reinterpret_cast<uint4*>(sK + kswz(k_r0 + 64, k_c8)) = kst2;                                      \
-        *reinterpret_cast<uint4*>(sK + kswz(k_r0 + 96, k_c8)) = kst3;                                      \
         FA_VROW(0, x, 0) FA_VROW(1, x, 1) FA_VROW(2, y, 0) FA_VROW(3, y, 1)                                \
         FA_VROW(4, z, 0) FA_VROW(5, z, 1) FA_VROW(6, w, 0) FA_VROW(7, w, 1)                                \
     }
 
     const int nstages = (a.Nk + KV_STAGE - 1) / KV_STAGE;
-    FA_GLOAD(0)
+    FA_GLOAD(0, 0)
     for (int t = 0; t < nstages; ++t) {
-        __syncthreads();  // previous stage fully consumed
+        const h16* sK = sKbuf + (t & 1) * (KV_STAGE * 64);
+        __syncthreads();  // previous stage fully consumed (sVt and the other sK buffer are free)
         FA_LSTORE()
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's K DMA has landed (the compiler does not track DMA -> LDS)
         __syncthreads();
-        if (t + 1 < nstages) FA_GLOAD((t + 1) * KV_STAGE)
+        if (t + 1 < nstages) FA_GLOAD((t + 1) * KV_STAGE, (t + 1) & 1)
         auto process = [&](auto SubC) __attribute__((always_inline)) {
             constexpr int sub = decltype(SubC)::value;
             const int key0 = t * KV_STAGE + sub * 64;
-            // ---- S^T = K Q^T : two 32-key blocks
-            f32x16 s_acc[2];
+            // ---- S^T = K Q^T - m_run : two 32-key blocks x QB query blocks (one K fragment read per QB MFMAs).  The running
+            // reference m_run of the lane's query is folded into the accumulator init, so the exponent argument comes straight
+            // out of the MFMA (no per-element subtract); the very first sub-tile starts from 0 and sets the reference.
+            const bool first = key0 == 0;
+            f32x16 s_acc[QB][2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+                for (int qb = 0; qb < QB; ++qb) {
+                    const float init = -m_run[qb];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s_acc[qb][kb][r] = init;
+                }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int r = sub * 64 + kb * 32 + l31;
                     const h16x8 kf = *reinterpret_cast<const h16x8*>(sK + kswz(r, ks * 2 + hh));
-                    s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s_acc[kb], 0, 0, 0);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], s_acc[qb][kb], 0, 0, 0);
                 }
             }
             // ---- online softmax (lane-local query); masking only on the ragged last sub-tile
-            float mt = -1.0e30f;
-            if (key0 + 64 > a.Nk) {
+            h16x8 pf[QB][2][2];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float mt = -1.0e30f;   // tile maximum relative to m_run
+                if (key0 + 64 > a.Nk) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                            const float sv = (key < a.Nk) ? s_acc[qb][kb][r] : -1.0e30f;
+                            s_acc[qb][kb][r] = sv;
+                            mt = fmaxf(mt, sv);
+                        }
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s_acc[qb][kb][r]);
+                }
+                mt = fmaxf(mt, __shfl_xor(mt, 32));
+                // deferred rescale (wave-uniform decision): everything still at the old reference is scaled exactly once
+                if (first || __any(mt > RESCALE_THR)) {
+                    const float delta = first ? mt : fmaxf(mt, 0.f);
+                    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // nothing accumulated yet on the first tile
+                    m_run[qb] += delta;
+                    l_run[qb] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o_acc[qb][d][r] *= alpha;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s_acc[qb][kb][r] -= delta;
+                }
+                float psum = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        const float sv = (key < a.Nk) ? s_acc[kb][r] : -1.0e30f;
-                        s_acc[kb][r] = sv;
-                        mt = fmaxf(mt, sv);
+                        const float p = __builtin_amdgcn_exp2f(s_acc[qb][kb][r]);
+                        psum += p;
+                        pf[qb][kb][r >> 3][r & 7] = (h16)p;
                     }
-            } else {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s_acc[kb][r]);
+                l_run[qb] += psum;
             }
-            mt = fmaxf(mt, __shfl_xor(mt, 32));
-            // deferred rescale (wave-uniform decision): everything still at the old max is scaled exactly once
-            if (__any(mt > m_run + RESCALE_THR)) {
-                const float m_new = fmaxf(m_run, mt);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
-            }
-            float psum = 0.f;
-            h16x8 pf[2][2];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s_acc[kb][r] - m_run);
-                    psum += p;
-                    pf[kb][r >> 3][r & 7] = (h16)p;
-                }
-            l_run += psum;
-            // ---- O^T += V^T P^T
+            // ---- O^T += V^T P^T (one V^T fragment read per QB MFMAs)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -176,7 +209,9 @@ __global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const AttnArgs a) 
                         h16x8 vf;
                         vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                         vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                        o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][k2], o_acc[d], 0, 0, 0);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+                            o_acc[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kb][k2], o_acc[qb][d], 0, 0, 0);
                     }
                 }
         };
@@ -185,20 +220,23 @@ __global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const AttnArgs a) 
     }
 
     // ---- normalise and store: lane owns query l31, d = 32*dblk + 8g + 4hh + e
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.f / l_tot;
-    const int qrow = qbase + l31;
-    if (qrow < a.Nq) {
-        h16* op = a.o + (size_t)n * a.so + (size_t)qrow * a.ldo + head * 64;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+        const float inv = 1.f / l_tot;
+        const int qrow = qbase + qb * 32 + l31;
+        if (qrow < a.Nq) {
+            h16* op = a.o + (size_t)n * a.so + (size_t)qrow * a.ldo + head * 64;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                h16x4 o;
+            for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (h16)(o_acc[d][4 * g + e] * inv);
-                *reinterpret_cast<h16x4*>(op + d * 32 + 8 * g + 4 * hh) = o;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    h16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (h16)(o_acc[qb][d][4 * g + e] * inv);
+                    *reinterpret_cast<h16x4*>(op + d * 32 + 8 * g + 4 * hh) = o;
+                }
+        }
     }
 }
 
@@ -242,8 +280,18 @@ __global__ __launch_bounds__(64) void attn_single_query_kernel(const h16* __rest
 
 int ladi_launch_flash_attn64(const AttnArgs& a, hipStream_t st) {
     if ((a.ldq & 7) || (a.ldk & 7) || (a.ldv & 7) || (a.ldo & 3) || a.Nk <= 0 || a.Nq <= 0) return -1;
-    dim3 grid((a.Nq + 127) / 128, a.heads, a.n);
-    hipLaunchKernelGGL(flash_attn64_kernel, grid, dim3(256), 0, st, a);
+    static const int force_qb = getenv("LADI_ATTN_QB") ? atoi(getenv("LADI_ATTN_QB")) : 0;
+    // two query blocks per wave once the 256-query tiles alone oversubscribe the 256 CUs and the K/V stream is long
+    // (measured on the UNet shapes, n = 16: self L0 594 -> 623 TFLOP/s, self L1 452 -> 494; short K/V or few tiles: no gain)
+    const long long tiles256 = (long long)(a.Nq / 256) * a.heads * a.n;
+    const bool qb2 = force_qb ? force_qb == 2 : (tiles256 >= 400 && a.Nk >= 256);
+    if (qb2) {
+        dim3 grid((a.Nq + 255) / 256, a.heads, a.n);
+        hipLaunchKernelGGL(flash_attn64_kernel<2>, grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid((a.Nq + 127) / 128, a.heads, a.n);
+        hipLaunchKernelGGL(flash_attn64_kernel<1>, grid, dim3(256), 0, st, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 

@@ -185,7 +185,8 @@ def test_softmax_rows(lib):
 
 
 # --------------------------------------------------------------------------------------------------------------- attention
-@pytest.mark.parametrize("n,heads,Nq,Nk", [(2, 2, 192, 192), (1, 5, 300, 77), (2, 1, 48, 48), (1, 3, 768, 768), (1, 2, 33, 130)])
+@pytest.mark.parametrize("n,heads,Nq,Nk", [(2, 2, 192, 192), (1, 5, 300, 77), (2, 1, 48, 48), (1, 3, 768, 768), (1, 2, 33, 130),
+                                            (4, 10, 2600, 300)])   # last: two query blocks per wave (>= 400 tiles of 256 queries), ragged both ways
 def test_flash_attention(lib, n, heads, Nq, Nk):
     C = heads * 64
     q, k, v = _rand((n, Nq, C), 40), _rand((n, Nk, C), 41), _rand((n, Nk, C), 42)
@@ -212,6 +213,21 @@ def test_flash_attention_forced_rescale(lib):
     assert lib.ladi_op_attention(ptr(Q), ptr(K), ptr(V), ptr(O), C, C, C, C, Nq * C, Nk * C, Nk * C, Nq * C, n, heads, Nq, Nk, 0.125, stream_ptr()) == 0
     torch.cuda.synchronize()
     assert U.rel_l2(O.float().cpu(), ref) < 3e-3
+
+
+def test_flash_attention_forced_rescale_two_query_blocks(lib):
+    """same as above on the 64-queries-per-wave variant; the spike hits only the second query block of one wave"""
+    n, heads, Nq, Nk, C = 8, 5, 2560, 320, 320
+    q, k, v = _rand((n, Nq, C), 143), _rand((n, Nk, C), 144), _rand((n, Nk, C), 145)
+    k[3, 300, 64:128] = q[3, 40, 64:128] * 6.0     # head 1, query 40 (second 32-query block of wave 0), key 300 (last stage)
+    qh, kh, vh = (t.view(n, -1, heads, 64).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(n, Nq, C)
+    Q, K, V = q.half().to(U.dev()), k.half().to(U.dev()), v.half().to(U.dev())
+    O = torch.empty((n, Nq, C), dtype=torch.float16, device=U.dev())
+    assert lib.ladi_op_attention(ptr(Q), ptr(K), ptr(V), ptr(O), C, C, C, C, Nq * C, Nk * C, Nk * C, Nq * C, n, heads, Nq, Nk, 0.125, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert U.rel_l2(O.float().cpu(), ref) < 3e-3
+    assert U.rel_l2(O[3, 32:64, 64:128].float().cpu(), ref[3, 32:64, 64:128]) < 3e-3
 
 
 # --------------------------------------------------------------------------------------------------------------- misc
