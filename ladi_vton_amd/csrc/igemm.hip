@@ -33,12 +33,6 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int V> struct IntC { static constexpr int value = V; };
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(IntC<I>{}); static_for<I + 1, N>(f); }
-}
-
 template <int BK>
 __device__ __forceinline__ int swz(int row, int chunk) {
     if constexpr (BK == 64) return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
@@ -453,7 +447,7 @@ bool ensure_ws(size_t bytes, hipStream_t st) {
 
 struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; int base; int split; };
 // cfg 1..6 (0 = auto)
-constexpr int NCFG = 22;
+constexpr int NCFG = 27;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1},
     {128, 256, 2, true, 0.80f, 4, 1, 1},   // 1: <2,2,2,4> BK32 NST3
@@ -478,6 +472,13 @@ const CfgInfo kCfg[NCFG + 1] = {
     {256, 128, 2, true, 0.00f, 2, 20, 1},   // 20: <4,2,2,2> BK32 NST3   8 waves
     {256, 256, 2, true, 0.00f, 2, 21, 1},   // 21: <2,4,4,2> BK32 NST3   8 waves, 96 KB LDS (1 workgroup / CU; listed as 2 so the tuner tries it)
     {320, 256, 2, false, 0.00f, 2, 22, 1},  // 22: <2,4,5,2> BK64 NST2   8 waves, 144 KB LDS
+    // 23..27: X-stationary linear kernel (linear_xs.hip; K = 320 / 640 token-wise projections).  bq field = channel slices
+    // over gridDim.y, tp field = 32-pixel blocks per wave
+    {1, 256, 2, false, 0.00f, 2, 23, 1},    // 23: 64 pixels / wave, 1 channel slice
+    {2, 256, 2, false, 0.00f, 2, 23, 1},    // 24: 64 pixels / wave, 2 channel slices
+    {1, 128, 2, true, 0.00f, 1, 23, 1},     // 25: 32 pixels / wave, 1 channel slice   (25..27 also: residual, GEGLU)
+    {2, 128, 2, true, 0.00f, 1, 23, 1},     // 26: 32 pixels / wave, 2 channel slices
+    {5, 128, 2, true, 0.00f, 1, 23, 1},     // 27: 32 pixels / wave, 5 channel slices
 };
 
 template <int WQ, int WP, int TQ, int TP, int BK, int NST>
@@ -552,6 +553,7 @@ int ladi_igemm_num_cfgs() { return NCFG; }
 
 int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st, int* stats_row_px) {
     IGemmArgs a = a_in;
+    const int cfg_in = cfg;
     if (stats_row_px) *stats_row_px = 0;
     if (a.ksize != 1 && a.ksize != 3) return -1;
     if ((a.C0 % 32) || (a.C1 % 32)) return -2;
@@ -563,7 +565,10 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     // ---- measured tile-shape selection ("measure, don't guess"): the first time a problem shape is seen outside a stream
     //      capture, every admissible configuration is timed with HIP events on the launch stream and the fastest is cached.
     //      Re-running a launch is idempotent (outputs never alias inputs in this library).
-    TuneKey key{a.P, a.Q, a.K, a.C0, a.C1, a.Wo, (a.ksize << 8) | (a.stride << 4) | (a.ups << 2) | (geglu ? 1 : 0), batch};
+    // flags also carry the epilogue features that decide which kernels are admissible (residuals, fused statistics, other)
+    const int epi = ((a.res0 || a.res1) ? 2 : 0) | (a.stats ? 8 : 0) |
+                    ((a.rowadd || a.mask || a.bias_per_pixel || a.out_f32 || a.out_scale != 1.f || (a.act != LADI_ACT_NONE && !geglu)) ? 64 : 0);
+    TuneKey key{a.P, a.Q, a.K, a.C0, a.C1, a.Wo, (a.ksize << 8) | (a.stride << 4) | (a.ups << 2) | (geglu ? 1 : 0) | epi, batch};
     if (cfg == 0 && g_autotune) {
         tune_cache_load();
         auto it = g_tuned.find(key);
@@ -578,6 +583,13 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                     float best_ms = 1e30f; int best_cfg = 0;
                     for (int c = 1; c <= NCFG; ++c) {
                         if (kCfg[c].blocks_per_cu < 2) continue;                       // 1-block/CU shapes never won
+                        float penalty_ms = 0.f;
+                        if (kCfg[c].base == 23) {
+                            IGemmArgs t = a; t.stats = nullptr;
+                            if (!ladi_linear_xs_eligible(t, batch, kCfg[c].tp, kCfg[c].bq)) continue;
+                            // no fused statistics there: charge the separate statistics pass the consumer then needs (~3 TB/s read)
+                            if (a.stats) penalty_ms = 3.f * (float)((double)a.P * a.Q * 2.0 / 3.0e9);
+                        } else {
                         if (geglu && !kCfg[c].geglu_ok) continue;
                         if (((c >= 7 && c <= 15) || c == 22) && ((a.C0 % 64) || (a.C1 % 64))) continue;
                         if (kCfg[c].bq > 2 * a.Q && kCfg[c].bq > 64) continue;        // grossly oversized in Q
@@ -585,13 +597,14 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                             const long long tiles = (long long)((a.Q + kCfg[c].bq - 1) / kCfg[c].bq) * ((a.P + kCfg[c].bp - 1) / kCfg[c].bp);
                             if (tiles * kCfg[c].split > 1024 || tiles > 256 || (a.K / 64) / kCfg[c].split < 8) continue;
                         }
+                        }
                         if (ladi_launch_igemm(a, batch, c, st) != 0) continue;          // warm-up (also sets function attributes)
                         (void)hipEventRecord(e0, st);
                         for (int r = 0; r < 3; ++r) (void)ladi_launch_igemm(a, batch, c, st);
                         (void)hipEventRecord(e1, st);
                         if (hipEventSynchronize(e1) != hipSuccess) continue;
                         float ms = 0.f;
-                        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best_cfg = c; }
+                        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms + penalty_ms < best_ms) { best_ms = ms + penalty_ms; best_cfg = c; }
                     }
                     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
                     if (best_cfg) { g_tuned[key] = best_cfg; cfg = best_cfg; tune_cache_append(key, best_cfg); }
@@ -600,12 +613,16 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
             }
         }
     }
+    if (cfg >= 1 && cfg <= NCFG && kCfg[cfg].base == 23 && cfg_in == 0) {   // stale cache entry / shape drift: fall back to the model
+        IGemmArgs t = a; t.stats = nullptr;
+        if (!ladi_linear_xs_eligible(t, batch, kCfg[cfg].tp, kCfg[cfg].bq)) cfg = 0;
+    }
     if (cfg == 0) {
         // fallback cost model: (waves of workgroups over the chip) x (tile work) / (per-tile efficiency)
         double best = 1e300;
         for (int c = 1; c <= NCFG; ++c) {
             const CfgInfo& ci = kCfg[c];
-            if (geglu && !ci.geglu_ok) continue;
+            if ((geglu && !ci.geglu_ok) || ci.base == 23) continue;
             const long long tiles = (long long)((a.Q + ci.bq - 1) / ci.bq) * ((a.P + ci.bp - 1) / ci.bp) * batch;
             const long long slots = 256LL * ci.blocks_per_cu;
             const double waves = (double)((tiles + slots - 1) / slots);
@@ -617,6 +634,10 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         }
     }
     if (cfg < 1 || cfg > NCFG) return -7;
+    if (kCfg[cfg].base == 23) {   // X-stationary linear kernel: no fused statistics (the consumer falls back to ladi_launch_gn_partial)
+        a.stats = nullptr;
+        if (!ladi_linear_xs_eligible(a, batch, kCfg[cfg].tp, kCfg[cfg].bq)) return -14;
+    }
     if (geglu && !kCfg[cfg].geglu_ok) return -8;
     if (((cfg >= 7 && cfg <= 15) || cfg == 22) && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
     const int split = kCfg[cfg].split;
@@ -664,6 +685,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         case 20: rc = launch_cfg<4, 2, 2, 2, 32, 3>(a, batch_l, st); break;
         case 21: rc = launch_cfg<2, 4, 4, 2, 32, 3>(a, batch_l, st); break;
         case 22: rc = launch_cfg<2, 4, 5, 2, 64, 2>(a, batch_l, st); break;
+        case 23: rc = ladi_launch_linear_xs(a, kCfg[cfg].tp, kCfg[cfg].bq, st); break;
         default: rc = -7;
     }
     if (rc == 0 && split > 1) {

@@ -9,6 +9,10 @@
 // *stats_row_px pixels per row (a multiple of 32 chosen with the tile shape; 0 = not produced, use ladi_launch_gn_partial)
 int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st, int* stats_row_px = nullptr);
 
+// ---- linear_xs.hip: X-stationary kernel for 1x1 layers with K = 320 / 640 (reached through ladi_launch_igemm cfg 23..27)
+bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs);
+int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st);
+
 // ---- norm.hip
 // GroupNorm in three stages (all atomics-free): per-channel partial statistics rows [rows][C][2] (written by the producing
 // igemm's epilogue, or by ladi_launch_gn_partial), finalize -> scale_shift[n][C0+C1][2], apply.

@@ -32,6 +32,70 @@ def test_conv3x3_eight_wave_tiles(cfg):
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
 
 
+@pytest.mark.parametrize("cfg,C,Q,hw", [(23, 320, 320, (32, 16)), (24, 320, 960, (32, 24)), (25, 320, 320, (16, 24)), (26, 640, 640, (16, 16)),
+                                        (27, 640, 1920, (8, 16)), (25, 640, 96, (16, 8)), (27, 320, 160, (16, 16))])
+def test_linear_x_stationary(cfg, C, Q, hw):
+    """X-stationary linear kernel (pixel panel in registers, weights streamed): asymmetric weights catch any fragment /
+    swizzle / channel-slice mix-up, random weights + bias check the arithmetic"""
+    N, (H, W) = 1, hw
+    x = _rand((N, C, H, W), 80)
+    w = _rand((Q, C, 1, 1), 81, 1 / math.sqrt(C))
+    for q in range(Q):
+        w[q, (q * 7 + 3) % C, 0, 0] += 1.0 + (q % 5)
+    b = _rand((Q,), 82, 0.1)
+    ref = F.conv2d(x, w, b)
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(w), Q, ksize=1, bias=b, cfg=cfg)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+
+
+@pytest.mark.parametrize("cfg,C,Q,hw", [(25, 320, 320, (16, 16)), (26, 320, 640, (16, 24)), (27, 640, 640, (16, 8)), (25, 640, 64, (8, 16)),
+                                        (27, 320, 160, (16, 8))])
+def test_linear_x_stationary_residual(cfg, C, Q, hw):
+    """residual tile arriving by LDS-DMA one channel block ahead (double-buffered landing patch, counted vmcnt hand-over);
+    must agree BIT-EXACTLY with the tiled igemm epilogue (same rounding points)"""
+    N, (H, W) = 1, hw
+    x = _rand((N, C, H, W), 90)
+    w = _rand((Q, C, 1, 1), 91, 1 / math.sqrt(C))
+    for q in range(Q):
+        w[q, (q * 11 + 5) % C, 0, 0] += 1.0 + (q % 3)
+    b, res = _rand((Q,), 92, 0.1), _rand((N, Q, H, W), 93)
+    ref = F.conv2d(x, w, b) + res
+    xs, ws, rs = U.nhwc16(x), U.pack_conv_weight(w), U.nhwc16(res)
+    y = U.igemm(xs, ws, Q, ksize=1, bias=b, res0=rs, cfg=cfg)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+    y_tiled = U.igemm(xs, ws, Q, ksize=1, bias=b, res0=rs, cfg=3)
+    assert torch.equal(y, y_tiled)
+
+
+@pytest.mark.parametrize("cfg,C,Qh,T", [(25, 320, 256, 256), (26, 320, 1280, 128), (27, 640, 320, 384), (25, 640, 32, 128)])
+def test_linear_x_stationary_geglu(cfg, C, Qh, T):
+    """GEGLU up-projection: interleaved u | g weight blocks, out = (u + bu) * gelu(g + bg)"""
+    x, w, b = _rand((1, C, T, 1), 94), _rand((2 * Qh, C), 95, 1 / math.sqrt(C)), _rand((2 * Qh,), 96, 0.1)
+    t = x[0, :, :, 0].t()
+    u, g = F.linear(t, w, b).chunk(2, -1)
+    ref = u * F.gelu(g)
+    wi, bi = torch.zeros_like(w), torch.zeros_like(b)
+    for j in range(Qh):
+        blk, i = divmod(j, 32)
+        wi[blk * 64 + i], wi[blk * 64 + 32 + i] = w[j], w[Qh + j]
+        bi[blk * 64 + i], bi[blk * 64 + 32 + i] = b[j], b[Qh + j]
+    y = U.igemm(U.nhwc16(x), wi.half().contiguous().to(U.dev()), 2 * Qh, ksize=1, bias=bi, act="geglu", cfg=cfg)
+    assert U.rel_l2(y.float().cpu().reshape(T, Qh), ref) < TOL
+
+
+def test_linear_x_stationary_rejects_unsupported():
+    """explicitly requested on a shape / epilogue it does not cover -> error, never a silent wrong answer"""
+    x = _rand((1, 320, 8, 8), 83)            # 64 pixels: not a whole 128-pixel panel
+    w = _rand((320, 320, 1, 1), 84, 0.05)
+    with pytest.raises(Exception):
+        U.igemm(U.nhwc16(x), U.pack_conv_weight(w), 320, ksize=1, cfg=25)
+    x = _rand((1, 320, 16, 16), 85)
+    with pytest.raises(Exception):                          # residual only with 32 pixels per wave
+        U.igemm(U.nhwc16(x), U.pack_conv_weight(w), 320, ksize=1, res0=U.nhwc16(x), cfg=23)
+    with pytest.raises(Exception):                          # no fused activation other than GEGLU
+        U.igemm(U.nhwc16(x), U.pack_conv_weight(w), 320, ksize=1, act="silu", cfg=25)
+
+
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 16, 17, 18, 19, 20, 21, 22])
 def test_mfma_layout_asymmetric(cfg):
     """transpose-detecting check of the MFMA fragment / accumulator mapping: 1x1 'conv' with an asymmetric weight."""

@@ -24,11 +24,15 @@ SHAPES = [
     ("unet lin 320->320 T3072", 3072, 1, 320, 320, 1),
     ("unet lin 320->2560 T3072 (geglu)", 3072, 1, 320, 2560, 1),
     ("unet lin 1280->320 T3072", 3072, 1, 1280, 320, 1),
-    ("unet lin 640->5120 T768", 768, 1, 640, 5120, 1),
+    ("unet lin 640->5120 T768 (geglu)", 768, 1, 640, 5120, 1),
     ("unet lin 1280->10240 T192", 192, 1, 1280, 10240, 1),
     ("unet lin 5120->1280 T192", 192, 1, 5120, 1280, 1),
     ("unet lin 1280->1280 T192", 192, 1, 1280, 1280, 1),
     ("unet lin 640->640 T768", 768, 1, 640, 640, 1),
+    ("unet lin 320->960 T3072 (qkv)", 3072, 1, 320, 960, 1),
+    ("unet lin 320->320 T3072 +res", 3072, 1, 320, 320, 1),
+    ("unet lin 640->640 T768 +res", 768, 1, 640, 640, 1),
+    ("unet lin 640->1920 T768 (qkv)", 768, 1, 640, 1920, 1),
 ]
 VAE_SHAPES = [
     ("vae conv3 128->128 @512x384", 512, 384, 128, 128, 3),
@@ -50,6 +54,11 @@ def run(name, n, H, W, cin, cout, k, cfg, iters):
     d.ksize, d.stride, d.pad, d.ups = k, 1, k // 2, 0
     d.W, d.Q, d.K = w.data_ptr(), cout, k * k * cin
     d.out, d.ldo, d.out_scale = out.data_ptr(), cout, 1.0
+    if "geglu" in name:
+        d.act = 3
+        d.ldo = cout // 2
+    if "+res" in name:
+        d.res0, d.ldr0 = x.data_ptr(), cin
     st = stream_ptr()
     for _ in range(3):
         rc = lib.ladi_op_igemm(ctypes.byref(d), 1, cfg, st)
