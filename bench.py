@@ -88,9 +88,12 @@ def pmc_traffic(kernel_label):
     --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM). None if absent."""
     import re
     m = re.match(r"igemm_kernel<([0-9,]+)>", kernel_label)
-    if not m:
+    if m:
+        pat = "igemm_kernel<" + ", ".join(m.group(1).split(",")) + ">"
+    elif kernel_label.startswith("linear_xs_kernel"):
+        pat = "linear_xs_kernel"     # first (= most time-consuming) instantiation listed in the PMC summary
+    else:
         return None
-    pat = "igemm_kernel<" + ", ".join(m.group(1).split(",")) + ">"
     vals = {}
     for tag in ("fetch", "write"):
         path = os.path.join(ROOT, "profiles", "r01_pmc_%s_size.txt" % tag)
@@ -227,18 +230,24 @@ def main():
         lib.ladi_profile_igemm_enable(1)
         unet.time_forward(n, h, w, a.roofline_iters)   # 1 warm-up + roofline_iters timed forwards, all recorded
         lib.ladi_profile_igemm_enable(0)
-        prof = (ctypes.c_double * 72)()
-        lib.ladi_profile_igemm_collect(prof, 72)
+        prof = (ctypes.c_double * 128)()
+        lib.ladi_profile_igemm_collect(prof, 128)
         names = {1: "igemm_kernel<2,2,2,4,32,3> (Q128xP256)", 2: "igemm_kernel<2,2,5,2,32,2> (Q320xP128)", 3: "igemm_kernel<2,2,2,2,32,3> (Q128xP128)",
                  4: "igemm_kernel<2,2,2,1,32,3> (Q128xP64)", 5: "igemm_kernel<2,2,1,1,32,3> (Q64xP64)", 6: "igemm_kernel<2,2,4,2,32,3> (Q256xP128)"}
         per = {}
         names.update({7: "igemm_kernel<2,2,2,2,64,2> (Q128xP128 BK64)", 8: "igemm_kernel<2,2,2,4,64,2> (Q128xP256 BK64)", 9: "igemm_kernel<2,2,2,1,64,3> (Q128xP64 BK64)",
                       10: "igemm_kernel<2,2,5,2,64,2> (Q320xP128 BK64)"})
-        names.update({11: "cfg9 + split-K 2", 12: "cfg9 + split-K 4", 13: "cfg9 + split-K 8", 14: "cfg7 + split-K 2", 15: "cfg7 + split-K 4"})
+        names.update({11: "igemm_kernel<2,2,2,1,64,3> + split-K 2", 12: "igemm_kernel<2,2,2,1,64,3> + split-K 4", 13: "igemm_kernel<2,2,2,1,64,3> + split-K 8",
+                      14: "igemm_kernel<2,2,2,2,64,2> + split-K 2", 15: "igemm_kernel<2,2,2,2,64,2> + split-K 4"})
         names.update({16: "igemm_kernel<2,2,1,1,32,4> (Q64xP64 NST4)", 17: "igemm_kernel<2,2,2,1,32,4> (Q128xP64 NST4)", 18: "igemm_kernel<2,2,2,2,32,4> (Q128xP128 NST4)",
                       19: "igemm_kernel<2,4,2,2,32,3> (Q128xP256, 8 waves)", 20: "igemm_kernel<4,2,2,2,32,3> (Q256xP128, 8 waves)",
                       21: "igemm_kernel<2,4,4,2,32,3> (Q256xP256, 8 waves)", 22: "igemm_kernel<2,4,5,2,64,2> (Q320xP256, 8 waves)"})
-        for c_ in range(1, 23):
+        names.update({23: "linear_xs_kernel (64 px/wave, 1 channel slice)", 24: "linear_xs_kernel (64 px/wave, 2 channel slices)",
+                      25: "linear_xs_kernel (32 px/wave, 1 channel slice)", 26: "linear_xs_kernel (32 px/wave, 2 channel slices)",
+                      27: "linear_xs_kernel (32 px/wave, 5 channel slices)"})
+        names.update({28: "igemm_kernel<4,2,2,2,32,3> + split-K 4", 29: "igemm_kernel<4,2,2,2,32,3> + split-K 8",
+                      30: "igemm_kernel<2,4,2,2,32,3> + split-K 4", 31: "igemm_kernel<2,4,2,2,32,3> + split-K 8"})
+        for c_ in range(1, 32):
             ms, fl, cnt = prof[c_ * 3], prof[c_ * 3 + 1], prof[c_ * 3 + 2]
             if cnt > 0:
                 per[c_] = dict(kernel=names[c_], launches=int(cnt), avg_ms=ms / cnt, flop_per_launch=fl / cnt, tflops=fl / ms / 1e9)

@@ -117,14 +117,18 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void igemm_kernel(const IGemmArgs 
     }
 
     // split-K: grid.z slices the K loop (a.splitk > 1); each slice writes an fp32 partial tile (see splitk_reduce_kernel)
+    // K-loop order: channel chunk OUTER, tap INNER.  The 9 taps of one channel chunk read overlapping input rows in consecutive
+    // steps, so all but the first hit in L2; tap-outer order re-streamed the whole pixel tile once per tap with a reuse distance
+    // (a full channel sweep x 32 co-resident workgroups per XCD) beyond the 4 MB L2.  Weights stay tap-major in memory: only the
+    // sequence of k offsets changes.
     int nk = a.K / BK;
+    const int ntap = a.ksize * a.ksize;
     int tap = 0, cb = 0;  // (tap, channel base) of the NEXT stage to issue
     if (a.splitk > 1) {
         const int sps = (nk + a.splitk - 1) / a.splitk;
         const int start = z * sps;
         nk = max(0, min(sps, nk - start));
-        const int kb = start * BK;
-        tap = kb / Ct; cb = kb - tap * Ct;
+        cb = (start / ntap) * BK; tap = start - (start / ntap) * ntap;
     }
 
     auto issue = [&](int stage) {
@@ -149,8 +153,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void igemm_kernel(const IGemmArgs 
             const unsigned vo = ok ? (unsigned)(((nb[i] + iy * a.Ws + ix) * ld + c) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sbase + (BQ * BK * 2) + i * (RPP * BK * 2)), 16, vo, 0, 0, 0);
         }
-        cb += BK;
-        if (cb >= Ct) { cb = 0; ++tap; }
+        if (++tap == ntap) { tap = 0; cb += BK; }
     };
 
     const int wq = wave / WP, wp = wave % WP;
@@ -447,7 +450,7 @@ bool ensure_ws(size_t bytes, hipStream_t st) {
 
 struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; int base; int split; };
 // cfg 1..6 (0 = auto)
-constexpr int NCFG = 27;
+constexpr int NCFG = 31;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1},
     {128, 256, 2, true, 0.80f, 4, 1, 1},   // 1: <2,2,2,4> BK32 NST3
@@ -479,6 +482,11 @@ const CfgInfo kCfg[NCFG + 1] = {
     {1, 128, 2, true, 0.00f, 1, 23, 1},     // 25: 32 pixels / wave, 1 channel slice   (25..27 also: residual, GEGLU)
     {2, 128, 2, true, 0.00f, 1, 23, 1},     // 26: 32 pixels / wave, 2 channel slices
     {5, 128, 2, true, 0.00f, 1, 23, 1},     // 27: 32 pixels / wave, 5 channel slices
+    // 28..31: 8-wave tiles + split-K for the deep-K, few-pixel levels (half the staging bytes per MAC of the 128x64 tile)
+    {256, 128, 2, false, 0.00f, 2, 20, 4},  // 28: cfg 20 + split-K 4
+    {256, 128, 2, false, 0.00f, 2, 20, 8},  // 29: cfg 20 + split-K 8
+    {128, 256, 2, false, 0.00f, 2, 19, 4},  // 30: cfg 19 + split-K 4
+    {128, 256, 2, false, 0.00f, 2, 19, 8},  // 31: cfg 19 + split-K 8
 };
 
 template <int WQ, int WP, int TQ, int TP, int BK, int NST>
