@@ -36,8 +36,18 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int head = blockIdx.y, n = blockIdx.z;
-    const int qbase = blockIdx.x * (128 * QB) + wave * (32 * QB);
+    // 1-D launch, XCD-aware: workgroup b runs on XCD b % 8 (round-robin dispatch), and all query tiles of one (sample, head) are
+    // placed on the SAME XCD so its K / V (re-read by every query tile) are fetched into one L2 instead of eight
+    int qt, head, n;
+    {
+        const int T = a.qtiles, G = a.heads * a.n;
+        const int b = blockIdx.x;
+        int g, t;
+        if (a.xcd_map && (G & 7) == 0) { const int x = b & 7, sl = b >> 3; g = x + 8 * (sl / T); t = sl - (sl / T) * T; }
+        else { g = b / T; t = b - g * T; }
+        qt = t; head = g % a.heads; n = g / a.heads;
+    }
+    const int qbase = qt * (128 * QB) + wave * (32 * QB);
 
     const h16* __restrict__ qp = a.q + (size_t)n * a.sq + head * 64;
     const h16* __restrict__ kp = a.k + (size_t)n * a.sk + head * 64;
@@ -285,12 +295,15 @@ int ladi_launch_flash_attn64(const AttnArgs& a, hipStream_t st) {
     // (measured on the UNet shapes, n = 16: self L0 594 -> 623 TFLOP/s, self L1 452 -> 494; short K/V or few tiles: no gain)
     const long long tiles256 = (long long)(a.Nq / 256) * a.heads * a.n;
     const bool qb2 = force_qb ? force_qb == 2 : (tiles256 >= 400 && a.Nk >= 256);
+    AttnArgs b = a;
+    static const bool no_xcd = getenv("LADI_ATTN_NOXCD") != nullptr;   // A/B switch for the XCD-aware mapping
+    b.xcd_map = no_xcd ? 0 : 1;
     if (qb2) {
-        dim3 grid((a.Nq + 255) / 256, a.heads, a.n);
-        hipLaunchKernelGGL(flash_attn64_kernel<2>, grid, dim3(256), 0, st, a);
+        b.qtiles = (a.Nq + 255) / 256;
+        hipLaunchKernelGGL(flash_attn64_kernel<2>, dim3((unsigned)(b.qtiles * a.heads * a.n)), dim3(256), 0, st, b);
     } else {
-        dim3 grid((a.Nq + 127) / 128, a.heads, a.n);
-        hipLaunchKernelGGL(flash_attn64_kernel<1>, grid, dim3(256), 0, st, a);
+        b.qtiles = (a.Nq + 127) / 128;
+        hipLaunchKernelGGL(flash_attn64_kernel<1>, dim3((unsigned)(b.qtiles * a.heads * a.n)), dim3(256), 0, st, b);
     }
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }

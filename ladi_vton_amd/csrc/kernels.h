@@ -35,6 +35,7 @@ struct AttnArgs {
     long long sq, sk, sv, so;               // per-sample strides (elements)
     int n, heads, Nq, Nk;                   // head h lives at column offset h*64 of each row
     float scale;
+    int qtiles, xcd_map;                    // set by the launcher: query tiles per (sample, head); XCD-aware workgroup order
 };
 int ladi_launch_flash_attn64(const AttnArgs& a, hipStream_t st);
 // single query per (sample, head): q [n][ldq], k/v [n][Nk][ld], generic head dim d <= 128

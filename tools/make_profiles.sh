@@ -16,3 +16,9 @@ python tools/rocpd_pmc.py $(find gpurun_out/pmc_w -name "*.db" | head -1) gpurun
 find gpurun_out -name "*.db" -delete
 rm -rf gpurun_out/kt gpurun_out/pmc_f gpurun_out/pmc_w
 head -c 600 gpurun_out/bench_default.json; echo; tail -3 gpurun_out/bench_default.err; head -8 gpurun_out/kstats.txt; head -5 gpurun_out/pmc_fetch.txt
+# extra bench points quoted in BASELINE.md §4 / README.md
+timeout 300 python bench.py --scheduler ddim --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/bench_ddim.json
+unset LADI_TUNE_CACHE
+timeout 500 python bench.py --batch 32 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/bench_b32.json
+timeout 500 python bench.py --height 1024 --width 768 --batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/bench_1024x768_b4.json
+for f in bench_ddim bench_b32 bench_1024x768_b4; do head -c 150 gpurun_out/$f.json; echo; done
