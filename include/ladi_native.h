@@ -113,6 +113,25 @@ void ladi_adapter_destroy(ladi_adapter* a);
 int ladi_adapter_forward(ladi_adapter* a, const void* x_dev, int B, int T, void* out_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * CLIP text encoder with pseudo-word splice — replaces src/utils/encode_text_word_embedding.py encode_text_word_embedding
+ * (:6-72; call site src/inference.py:291-295) and the transformers CLIPTextModel it drives (SD2 text encoder: 23 layers, 1024-d,
+ * 16 heads, gelu MLP 4096, 77 positions, causal).  SURVEY.md §8(f) rank 1: the producer of `prompt_embeds`.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct { int vocab_size, hidden, heads, mlp_dim, layers, max_positions, vstar_token_id; float layer_norm_eps; } ladi_text_config;
+typedef struct ladi_text_encoder ladi_text_encoder;
+/* weights: transformers-4.27 key layout (text_model.embeddings.*, text_model.encoder.layers.N.*, text_model.final_layer_norm.*);
+ * the flattened layout without the text_model. prefix is accepted too */
+ladi_text_encoder* ladi_text_encoder_create(const ladi_text_config* cfg, const ladi_weights* ws);
+void ladi_text_encoder_destroy(ladi_text_encoder* t);
+/* input_ids_host: [B][T] int32 in HOST memory (tokenizer output); word_embeddings_dev: fp16 [B][num_vstar][hidden] or NULL (no splice).
+ * In every sentence containing vstar_token_id ('$' = 259) the num_vstar positions starting at its FIRST occurrence are replaced by that
+ * sentence's pseudo-word embeddings (:12-35); slots running past T are an error (the reference raises IndexError).
+ * out_hidden_dev: fp16 [B][T][hidden] = final_layer_norm(encoder output) (:56-57); out_pooled_dev: fp16 [B][hidden] = row at
+ * argmax(input_ids) (:62-65), or NULL. */
+int ladi_text_encoder_forward(ladi_text_encoder* t, const int* input_ids_host, int B, int T, const void* word_embeddings_dev,
+                              int num_vstar, void* out_hidden_dev, void* out_pooled_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Scheduler — replaces diffusers DDIMScheduler / PNDMScheduler (skip_prk_steps) set_timesteps + step
  * (tryon_pipe.py:650-651,740).  kind: 0 = DDIM, 1 = PNDM.
  * ------------------------------------------------------------------------------------------------------------- */
@@ -183,6 +202,10 @@ int ladi_op_group_norm(const void* src0, int C0, const void* src1, int C1, int n
 int ladi_op_layer_norm(const void* x, const void* gamma, const void* beta, float eps, int rows, int C, void* out, void* stream);
 int ladi_op_attention(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq,
                       long long sk, long long sv, long long so, int n, int heads, int Nq, int Nk, float scale, void* stream);
+/* same with causal = 1: query i attends to keys <= i (the CLIP text encoder's mask; Nq == Nk) */
+int ladi_op_attention_causal(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq,
+                             long long sk, long long sv, long long so, int n, int heads, int Nq, int Nk, float scale, int causal,
+                             void* stream);
 int ladi_op_softmax_rows(const float* S, int rows, int cols, float scale, void* P, void* stream);
 int ladi_op_small_linear(const void* x, int x_f32, int ldx, const void* W, const void* bias, const void* res, int ldr, int M, int N,
                          int K, int act, int pre_silu, void* out, int out_f32, int ldo, void* stream);

@@ -8,6 +8,7 @@ from ._lib import NativeError  # noqa: F401
 from .modules import (NativeEMASC, NativeInversionAdapter, NativeUNet, NativeVAE, mask_features)  # noqa: F401
 from .pipeline import StableDiffusionTryOnePipeline  # noqa: F401
 from .schedulers import DDIMScheduler, PNDMScheduler  # noqa: F401
+from .text import NativeCLIPTextEncoder, encode_text_word_embedding  # noqa: F401
 
 
 def build_random_init_pipeline(size="full", scheduler="ddim", with_emasc=True):

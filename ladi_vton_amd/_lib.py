@@ -38,6 +38,11 @@ class AdapterConfig(Structure):
                 ("layer_norm_eps", c_float)]
 
 
+class TextConfig(Structure):
+    _fields_ = [("vocab_size", c_int), ("hidden", c_int), ("heads", c_int), ("mlp_dim", c_int), ("layers", c_int), ("max_positions", c_int),
+                ("vstar_token_id", c_int), ("layer_norm_eps", c_float)]
+
+
 class TryOnInputs(Structure):
     _fields_ = [("batch", c_int), ("height", c_int), ("width", c_int), ("in_dtype", c_int),
                 ("image_dev", c_void_p), ("mask_image_dev", c_void_p), ("pose_map_dev", c_void_p), ("warped_cloth_dev", c_void_p),
@@ -86,6 +91,9 @@ SIGNATURES = {
     "ladi_adapter_create": (_P, [POINTER(AdapterConfig), _P]),
     "ladi_adapter_destroy": (None, [_P]),
     "ladi_adapter_forward": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "ladi_text_encoder_create": (_P, [POINTER(TextConfig), _P]),
+    "ladi_text_encoder_destroy": (None, [_P]),
+    "ladi_text_encoder_forward": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P, _P, _P]),
     "ladi_sched_timesteps": (c_int, [c_int, c_int, POINTER(c_int), c_int]),
     "ladi_sched_alphas_cumprod": (c_int, [POINTER(c_float)]),
     "ladi_tryon_create": (_P, [_P, _P, _P]),
@@ -100,6 +108,8 @@ SIGNATURES = {
     "ladi_op_layer_norm": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),
     "ladi_op_attention": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,
                                   c_int, c_int, c_int, c_int, c_float, _P]),
+    "ladi_op_attention_causal": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,
+                                         c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "ladi_op_softmax_rows": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
     "ladi_op_small_linear": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "ladi_op_nchw_to_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),

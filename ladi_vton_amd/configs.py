@@ -20,6 +20,9 @@ EMASC_FULL = dict(in_channels=(128, 128, 128, 256, 512), out_channels=(128, 256,
 EMASC_TINY = dict(in_channels=(64, 64, 64, 64, 128), out_channels=(64, 64, 128, 128, 128))
 ADAPTER_FULL = dict(hidden=1280, heads=16, mlp_dim=5120, head_hidden=5120, out_dim=16384, layer_norm_eps=1e-5)
 ADAPTER_TINY = dict(hidden=128, heads=2, mlp_dim=256, head_hidden=256, out_dim=16 * 128, layer_norm_eps=1e-5)
+# CLIP text encoder of stabilityai/stable-diffusion-2-inpainting (OpenCLIP ViT-H/14 text tower minus its last layer)
+TEXT_FULL = dict(vocab_size=49408, hidden=1024, heads=16, mlp_dim=4096, layers=23, max_positions=77, layer_norm_eps=1e-5, vstar_token_id=259)
+TEXT_TINY = dict(vocab_size=320, hidden=128, heads=2, mlp_dim=256, layers=2, max_positions=77, layer_norm_eps=1e-5, vstar_token_id=259)
 
 
 def emasc_for_vae(vae_cfg):
@@ -161,6 +164,24 @@ def emasc_shapes(cfg):
     for i, (ci, co) in enumerate(zip(cfg["in_channels"], cfg["out_channels"])):
         _conv(sd, "conv.%d.0" % i, ci, ci, 3)
         _conv(sd, "conv.%d.2" % i, ci, co, 3)
+    return sd
+
+
+def text_shapes(cfg):
+    """transformers 4.27 CLIPTextModel key layout (the layout of the released text_encoder checkpoint): text_model.*"""
+    sd = OrderedDict()
+    h = cfg["hidden"]
+    sd["text_model.embeddings.token_embedding.weight"] = (cfg["vocab_size"], h)
+    sd["text_model.embeddings.position_embedding.weight"] = (cfg["max_positions"], h)
+    for i in range(cfg["layers"]):
+        e = "text_model.encoder.layers.%d" % i
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            _lin(sd, e + ".self_attn." + n, h, h)
+        _norm(sd, e + ".layer_norm1", h)
+        _lin(sd, e + ".mlp.fc1", h, cfg["mlp_dim"])
+        _lin(sd, e + ".mlp.fc2", cfg["mlp_dim"], h)
+        _norm(sd, e + ".layer_norm2", h)
+    _norm(sd, "text_model.final_layer_norm", h)
     return sd
 
 

@@ -162,13 +162,16 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 float mt = -1.0e30f;   // tile maximum relative to m_run
-                if (key0 + 64 > a.Nk) {
+                if (key0 + 64 > a.Nk || a.causal) {
+                    // causal (CLIP text encoder): query i attends to keys <= i; key 0 is visible to every query, so the first
+                    // sub-tile always yields a finite reference
+                    const int klim = a.causal ? min(a.Nk, qbase + qb * 32 + l31 + 1) : a.Nk;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                            const float sv = (key < a.Nk) ? s_acc[qb][kb][r] : -1.0e30f;
+                            const float sv = (key < klim) ? s_acc[qb][kb][r] : -1.0e30f;
                             s_acc[qb][kb][r] = sv;
                             mt = fmaxf(mt, sv);
                         }

@@ -14,6 +14,7 @@ struct ladi_unet { UNet u; };
 struct ladi_vae { VAE v; };
 struct ladi_emasc { EMASC e; };
 struct ladi_adapter { Adapter a; };
+struct ladi_text_encoder { TextEncoder t; };
 struct ladi_tryon { TryOn t; };
 
 static_assert(sizeof(ladi_igemm_desc) == sizeof(IGemmArgs), "public igemm descriptor must mirror IGemmArgs");
@@ -308,6 +309,32 @@ int ladi_adapter_forward(ladi_adapter* a, const void* x, int B, int T, void* out
     return guarded("ladi_adapter_forward", [&]() { return a->a.forward(reinterpret_cast<const h16*>(x), B, T, reinterpret_cast<h16*>(out), S(stream)); });
 }
 
+// ------------------------------------------------------------------------------------------------ text encoder
+ladi_text_encoder* ladi_text_encoder_create(const ladi_text_config* cfg, const ladi_weights* ws) {
+    ladi_text_encoder* h = nullptr;
+    int rc = guarded("ladi_text_encoder_create", [&]() {
+        if (!cfg || !ws) throw std::runtime_error("null argument");
+        require_gpu();
+        TextCfg c; c.vocab = cfg->vocab_size; c.hidden = cfg->hidden; c.heads = cfg->heads; c.mlp = cfg->mlp_dim; c.layers = cfg->layers;
+        c.max_pos = cfg->max_positions; c.vstar_id = cfg->vstar_token_id; c.ln_eps = cfg->layer_norm_eps;
+        if (c.layers <= 0 || c.heads <= 0 || c.hidden % 64 || c.mlp % 64) throw std::runtime_error("text encoder: bad config");
+        h = new ladi_text_encoder();
+        h->t.load(c, ws->ws);
+        return 0;
+    });
+    if (rc) { delete h; return nullptr; }
+    return h;
+}
+void ladi_text_encoder_destroy(ladi_text_encoder* t) { delete t; }
+int ladi_text_encoder_forward(ladi_text_encoder* t, const int* ids, int B, int T, const void* wemb, int nv, void* out_hidden, void* out_pooled,
+                              void* stream) {
+    return guarded("ladi_text_encoder_forward", [&]() {
+        if (!t || !ids || !out_hidden) throw std::runtime_error("null argument");
+        if (wemb && nv <= 0) throw std::runtime_error("num_vstar must be positive when word embeddings are given");
+        return t->t.forward(ids, B, T, reinterpret_cast<const h16*>(wemb), nv, reinterpret_cast<h16*>(out_hidden), reinterpret_cast<h16*>(out_pooled), S(stream));
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ scheduler helpers
 int ladi_sched_timesteps(int kind, int steps, int* out, int cap) {
     return guarded("ladi_sched_timesteps", [&]() {
@@ -399,6 +426,16 @@ int ladi_op_attention(const void* q, const void* k, const void* v, void* o, int 
     a.q = (const h16*)q; a.k = (const h16*)k; a.v = (const h16*)v; a.o = (h16*)o;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.sq = sq; a.sk = sk; a.sv = sv; a.so = so;
     a.n = n; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    return ladi_launch_flash_attn64(a, S(stream));
+}
+int ladi_op_attention_causal(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq,
+                             long long sk, long long sv, long long so, int n, int heads, int Nq, int Nk, float scale, int causal,
+                             void* stream) {
+    if (causal && Nq != Nk) return -1;
+    AttnArgs a;
+    a.q = (const h16*)q; a.k = (const h16*)k; a.v = (const h16*)v; a.o = (h16*)o;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.sq = sq; a.sk = sk; a.sv = sv; a.so = so;
+    a.n = n; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale; a.causal = causal ? 1 : 0;
     return ladi_launch_flash_attn64(a, S(stream));
 }
 int ladi_op_softmax_rows(const float* Sm, int rows, int cols, float scale, void* P, void* stream) {

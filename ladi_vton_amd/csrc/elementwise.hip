@@ -422,6 +422,42 @@ int ladi_launch_mask_mul(h16* feat, int C, int n_pix, const h16* mask, hipStream
     return ok();
 }
 
+// CLIP text embeddings with the pseudo-word splice (encode_text_word_embedding.py:26-38): row (b,t) = token_embedding[ids[b][t]]
+// unless first[b] <= t < first[b] + nv (first[b] >= 0: position of sentence b's first '$'), then word_emb[b][t - first[b]]; plus
+// the position embedding of t.  One block per row, 8 channels per thread.
+__global__ void text_embed_kernel(const int* __restrict__ ids, const int* __restrict__ first, int nv, const h16* __restrict__ tok,
+                                  const h16* __restrict__ pos, const h16* __restrict__ wemb, int T, int H, h16* __restrict__ out) {
+    const int row = blockIdx.x, b = row / T, t = row - b * T;
+    const int f = first[b];
+    const bool sp = wemb && f >= 0 && t >= f && t < f + nv;
+    const h16* src = sp ? wemb + ((size_t)b * nv + (t - f)) * H : tok + (size_t)ids[row] * H;
+    const h16* pp = pos + (size_t)t * H;
+    for (int c = threadIdx.x * 8; c < H; c += blockDim.x * 8) {
+        const h16x8 a = *reinterpret_cast<const h16x8*>(src + c);
+        const h16x8 p8 = *reinterpret_cast<const h16x8*>(pp + c);
+        h16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (h16)((float)a[e] + (float)p8[e]);
+        *reinterpret_cast<h16x8*>(out + (size_t)row * H + c) = o;
+    }
+}
+// dst[i][:] = src[rows[i]][:]  (pooled output: the eot row of every sentence)
+__global__ void gather_rows_kernel(const h16* __restrict__ src, const int* __restrict__ rows, int H, h16* __restrict__ dst) {
+    const h16* s = src + (size_t)rows[blockIdx.x] * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) dst[(size_t)blockIdx.x * H + c] = s[c];
+}
+
+int ladi_launch_text_embed(const int* ids, const int* first, int nv, const h16* tok, const h16* pos, const h16* wemb, int B, int T,
+                           int H, h16* out, hipStream_t st) {
+    if (H % 8) return -1;
+    hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)(B * T)), dim3(128), 0, st, ids, first, nv, tok, pos, wemb, T, H, out);
+    return ok();
+}
+int ladi_launch_gather_rows(const h16* src, const int* rows, int n, int H, h16* dst, hipStream_t st) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, src, rows, H, dst);
+    return ok();
+}
+
 int ladi_launch_fill_f32(float* p, size_t n, float v, hipStream_t st) {
     hipLaunchKernelGGL(fill_f32_kernel, dim3(256), dim3(256), 0, st, p, n, v);
     return ok();

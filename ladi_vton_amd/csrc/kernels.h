@@ -35,7 +35,8 @@ struct AttnArgs {
     long long sq, sk, sv, so;               // per-sample strides (elements)
     int n, heads, Nq, Nk;                   // head h lives at column offset h*64 of each row
     float scale;
-    int qtiles, xcd_map;                    // set by the launcher: query tiles per (sample, head); XCD-aware workgroup order
+    int causal = 0;                         // 1: query i sees keys <= i (Nq == Nk)
+    int qtiles = 0, xcd_map = 0;            // set by the launcher: query tiles per (sample, head); XCD-aware workgroup order
 };
 int ladi_launch_flash_attn64(const AttnArgs& a, hipStream_t st);
 // single query per (sample, head): q [n][ldq], k/v [n][Nk][ld], generic head dim d <= 128
@@ -95,6 +96,11 @@ int ladi_launch_image_post(const h16* src, int ld, int n_pix, float* dst, hipStr
 // features[i] *= (1-mask) standalone (mask_features for the module-by-module shim path)
 int ladi_launch_mask_mul(h16* feat, int C, int n_pix, const h16* mask, hipStream_t st);
 int ladi_launch_fill_f32(float* p, size_t n, float v, hipStream_t st);
+// CLIP text embeddings + pseudo-word splice: ids [B][T] (device), first [B] = position of the sentence's first '$' or -1,
+// wemb fp16 [B][nv][H] or null; out [B][T][H] = (token | pseudo-word) embedding + position embedding
+int ladi_launch_text_embed(const int* ids, const int* first, int nv, const h16* tok, const h16* pos, const h16* wemb, int B, int T,
+                           int H, h16* out, hipStream_t st);
+int ladi_launch_gather_rows(const h16* src, const int* rows, int n, int H, h16* dst, hipStream_t st);
 // decoder input: post_quant_conv(lat / scaling_factor) -> NHWC fp16 padded to ld; pq = device [16 w | 4 b] or null (identity)
 int ladi_launch_post_quant(const float* lat, const float* pq, float inv_sf, int n, h16* dst, int ld, hipStream_t st);
 int ladi_launch_lat_nchw_to_pix(const float* src, int B, int hw, float scale, float* dst, hipStream_t st);

@@ -195,6 +195,21 @@ struct Adapter {
     int forward(const h16* x, int B, int T, h16* out, hipStream_t st);
 };
 
+// CLIP text encoder + pseudo-word splice (reference src/utils/encode_text_word_embedding.py:6-72)
+struct TextCfg { int vocab = 49408, hidden = 1024, heads = 16, mlp = 4096, layers = 23, max_pos = 77, vstar_id = 259; float ln_eps = 1e-5f; };
+struct TextLayer { DNorm ln1, ln2; DConv qkv, o, fc1, fc2; };
+struct TextEncoder {
+    TextCfg cfg; DevPool pool;
+    h16* tok = nullptr; h16* pos = nullptr;   // [vocab][hidden], [max_pos][hidden]
+    std::vector<TextLayer> layers; DNorm final_ln;
+    Arena arena;
+    int* d_ids = nullptr; int ids_cap = 0;    // ids [B*T] | first [B] | eot row [B]
+    void load(const TextCfg& c, const WeightStore& ws);
+    // ids_host [B][T]; word_emb fp16 [B][nv][hidden] (device) or null; out_hidden [B][T][hidden]; out_pooled [B][hidden] or null
+    int forward(const int* ids_host, int B, int T, const h16* word_emb, int nv, h16* out_hidden, h16* out_pooled, hipStream_t st);
+    ~TextEncoder();
+};
+
 struct TryOnInputs {
     int batch, height, width, in_f32;
     const void *image, *mask_image, *pose_map, *warped_cloth;

@@ -1,6 +1,7 @@
 """Generate the golden fixtures under tests/golden/ by running the REAL reference code where it is importable in the build
 container: src/models/emasc.py EMASC, src/utils/data_utils.py mask_features, and the installed
-transformers CLIPEncoderLayer (the class src/models/inversion_adapter.py:2,9 wraps; v5 call convention `layer(x, None)`).
+transformers CLIPEncoderLayer (the class src/models/inversion_adapter.py:2,9 wraps; v5 call convention `layer(x, None)`), and
+src/utils/encode_text_word_embedding.py on the installed transformers CLIPTextModel (through a 4.27-layout facade).
 
 Run here (needs /root/reference):  python -m oracle.make_golden
 The GPU box has no /root/reference: tests only read the committed .safetensors files.
@@ -65,7 +66,81 @@ def main():
         if isinstance(y, (tuple, list)):
             y = y[0]
     save_file({"x": x, "y": y.contiguous()}, os.path.join(OUT, "clip_encoder_layer_tiny.safetensors"))
+
+    make_text_golden(g)
     print("wrote", os.listdir(OUT))
+
+
+class _Emb42:
+    """transformers-4.27 view of CLIPTextEmbeddings: the attributes encode_text_word_embedding.py:26-37 reaches into"""
+    def __init__(self, emb, T):
+        self.token_embedding, self.position_embedding = emb.token_embedding, emb.position_embedding
+        self.position_ids = torch.arange(T).unsqueeze(0)
+
+
+class _Out42(tuple):
+    hidden_states = None
+    attentions = None
+
+
+class _TextModel42:
+    """transformers-4.27 `CLIPTextModel.text_model` facade over the installed (5.x, flattened) CLIPTextModel: same modules, same
+    arithmetic; only attribute names / call conventions are adapted so that the reference function runs unmodified"""
+    def __init__(self, m, T):
+        self.m, self.embeddings, self.final_layer_norm = m, _Emb42(m.embeddings, T), m.final_layer_norm
+
+    @staticmethod
+    def _build_causal_attention_mask(bsz, seq_len, dtype):   # modeling_clip.py (4.27.3) CLIPTextTransformer._build_causal_attention_mask
+        mask = torch.empty(bsz, seq_len, seq_len, dtype=dtype)
+        mask.fill_(torch.finfo(dtype).min)
+        mask.triu_(1)
+        return mask.unsqueeze(1)
+
+    def encoder(self, inputs_embeds, attention_mask, causal_attention_mask, output_attentions, output_hidden_states, return_dict):
+        out = self.m.encoder(inputs_embeds=inputs_embeds, attention_mask=causal_attention_mask, is_causal=True)
+        return _Out42((out.last_hidden_state,))
+
+
+def make_text_golden(g):
+    """tests/golden/clip_text_tiny.safetensors: the reference's own encode_text_word_embedding (imported, not copied) on the installed
+    transformers CLIPTextModel with the deterministic tiny checkpoint; rows with and without '$', num_vstar = 3"""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from src.utils.encode_text_word_embedding import encode_text_word_embedding  # noqa: E402  (reference code)
+    from ladi_vton_amd import configs as C
+    tc = C.TEXT_TINY
+    hc = CLIPTextConfig(vocab_size=tc["vocab_size"], hidden_size=tc["hidden"], intermediate_size=tc["mlp_dim"], num_hidden_layers=tc["layers"],
+                        num_attention_heads=tc["heads"], max_position_embeddings=tc["max_positions"], hidden_act="gelu",
+                        layer_norm_eps=tc["layer_norm_eps"], attention_dropout=0.0, bos_token_id=1, eos_token_id=2)
+    try:
+        hc._attn_implementation = "eager"
+    except Exception:
+        pass
+    m = CLIPTextModel(hc).eval()
+    sd = C.synth_state_dict(C.text_shapes(tc), "text.")
+    own = m.state_dict()
+    flat = {(k[len("text_model."):] if k[len("text_model."):] in own else k): v for k, v in sd.items()}
+    missing, unexpected = m.load_state_dict(flat, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    B, T, NV = 4, tc["max_positions"], 3
+    ids = torch.randint(3, 250, (B, T), generator=g)
+    ids[:, 0] = 300                                  # "bos"-like high id is NOT the argmax ...
+    eot = [20, 9, 40, 76]
+    for b in range(B):
+        ids[b, eot[b]] = 319                         # ... the highest id marks the pooled position (eot convention, :62-65)
+        ids[b, eot[b] + 1:] = 0
+    ids[0, 10:13] = 259                              # three consecutive '$' (the prompt template of inference.py:289)
+    ids[2, 5] = 259; ids[2, 30] = 259                # only the FIRST '$' of a sentence anchors the splice
+    # rows 1 and 3 have no '$': untouched
+    we = torch.randn((B, NV, tc["hidden"]), generator=g).half().float()
+    shim = type("TextEncoder42", (), {})()
+    shim.text_model = _TextModel42(m, T)
+    with torch.no_grad():
+        out = encode_text_word_embedding(shim, ids.clone(), we.clone(), NV)
+        plain = m(input_ids=ids)                     # sanity of the facade: without splice rows it must equal the model's own forward
+        out_nosplice = encode_text_word_embedding(shim, ids[[1, 3]].clone(), we[[1, 3]].clone(), NV)
+    assert torch.allclose(out_nosplice.last_hidden_state, plain.last_hidden_state[[1, 3]], atol=1e-5), "4.27 facade != installed forward"
+    save_file({"input_ids": ids.int(), "word_embeddings": we, "last_hidden_state": out.last_hidden_state.contiguous(),
+               "pooler_output": out.pooler_output.contiguous()}, os.path.join(OUT, "clip_text_tiny.safetensors"))
 
 
 if __name__ == "__main__":

@@ -69,6 +69,29 @@ def test_oracle_matches_transformers_clip_layer_fixture():
     assert torch.allclose(y, c["y"], atol=2e-5, rtol=1e-5)
 
 
+def test_text_oracle_matches_reference_golden():
+    """fixture = the reference's OWN encode_text_word_embedding (src/utils/encode_text_word_embedding.py) run on the installed
+    transformers CLIPTextModel (oracle/make_golden.py): '$' splice (first occurrence anchors, num_vstar = 3), rows without '$',
+    causal text transformer, final LayerNorm, pooled output at argmax(input_ids)"""
+    from oracle import text as T
+    c = load_file(os.path.join(GOLD, "clip_text_tiny.safetensors"))
+    sd = C.synth_state_dict(C.text_shapes(C.TEXT_TINY), "text.")
+    hs, pooled = T.clip_text_forward(sd, C.TEXT_TINY, c["input_ids"], c["word_embeddings"], 3)
+    assert torch.allclose(hs, c["last_hidden_state"], atol=3e-5, rtol=1e-5)
+    assert torch.allclose(pooled, c["pooler_output"], atol=3e-5, rtol=1e-5)
+    assert C.param_count(C.text_shapes(C.TEXT_FULL)) == 340_387_840          # SD2 text encoder (23-layer OpenCLIP ViT-H text tower)
+    # splice semantics in isolation: untouched rows, first-'$' anchoring, slots past the sequence end are an error
+    ids = c["input_ids"].long()
+    emb = torch.zeros((ids.shape[0], ids.shape[1], 4))
+    we = torch.arange(ids.shape[0] * 3 * 4, dtype=torch.float32).view(ids.shape[0], 3, 4) + 1
+    out = T.splice_word_embeddings(emb, ids, we, 3)
+    assert torch.equal(out[0, 10:13], we[0]) and torch.equal(out[2, 5:8], we[2]) and out[2, 30].abs().sum() == 0
+    assert out[1].abs().sum() == 0 and out[3].abs().sum() == 0
+    bad = ids.clone(); bad[1, 76] = 259
+    with pytest.raises(IndexError):
+        T.splice_word_embeddings(emb, bad, we, 3)
+
+
 def test_mask_features_progressive_equals_strided():
     """SURVEY.md §3.3: the progressive nearest chain equals mask[..., ::s, ::s] (what the native kernels implement)"""
     g = torch.Generator().manual_seed(0)

@@ -69,3 +69,28 @@ def test_full_adapter_vs_oracle():
     got = ad(x.to(U.dev())).float().cpu()
     assert got.shape == (3, 16384)
     assert U.psnr(got, ref) >= 50.0, U.psnr(got, ref)
+
+
+def test_full_text_encoder_vs_oracle():
+    """SD2 text encoder size (23 layers, 1024-d, 340.4 M parameters), the prompt template of src/inference.py:289 with 16 pseudo-words"""
+    import ladi_vton_amd as L
+    from oracle import text as T
+    cfg = C.TEXT_FULL
+    sd = C.synth_state_dict(C.text_shapes(cfg), "text.")
+    enc = L.NativeCLIPTextEncoder(cfg, sd)
+    B, T_, NV = 2, 77, 16
+    g = torch.Generator().manual_seed(21)
+    ids = torch.zeros((B, T_), dtype=torch.int32)
+    ids[:, 0] = 49406
+    for b in range(B):
+        n_words = 8 + b
+        ids[b, 1:1 + n_words] = torch.randint(300, 40000, (n_words,), generator=g).int()
+        ids[b, 1 + n_words:1 + n_words + NV] = 259
+        ids[b, 1 + n_words + NV] = 49407
+    we = torch.randn((B, NV, cfg["hidden"]), generator=g).half().float() * 0.05
+    ref, ref_pooled = T.clip_text_forward(sd, cfg, ids, we, NV)
+    out = L.encode_text_word_embedding(enc, ids, we.to(U.dev()), NV)
+    torch.cuda.synchronize()
+    got, pooled = out.last_hidden_state.float().cpu(), out.pooler_output.float().cpu()
+    assert U.psnr(got, ref) >= 45.0 and U.rel_l2(got, ref) <= 1e-2, (U.psnr(got, ref), U.rel_l2(got, ref))
+    assert U.rel_l2(pooled, ref_pooled) <= 1e-2

@@ -266,6 +266,22 @@ def test_flash_attention(lib, n, heads, Nq, Nk):
     assert U.rel_l2(O.float().cpu(), ref) < 3e-3
 
 
+@pytest.mark.parametrize("n,heads,T", [(2, 2, 77), (1, 3, 200), (4, 10, 2560)])   # last: 64-queries-per-wave variant, 20 key stages
+def test_flash_attention_causal(lib, n, heads, T):
+    """causal mask of the CLIP text encoder: query i sees keys <= i"""
+    C = heads * 64
+    q, k, v = _rand((n, T, C), 240), _rand((n, T, C), 241), _rand((n, T, C), 242)
+    qh, kh, vh = (t.view(n, T, heads, 64).transpose(1, 2) for t in (q, k, v))
+    mask = torch.full((T, T), float("-inf")).triu_(1)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125 + mask, -1) @ vh).transpose(1, 2).reshape(n, T, C)
+    Q, K, V = q.half().to(U.dev()), k.half().to(U.dev()), v.half().to(U.dev())
+    O = torch.empty((n, T, C), dtype=torch.float16, device=U.dev())
+    assert lib.ladi_op_attention_causal(ptr(Q), ptr(K), ptr(V), ptr(O), C, C, C, C, T * C, T * C, T * C, T * C, n, heads, T, T, 0.125, 1, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert U.rel_l2(O.float().cpu(), ref) < 3e-3
+    assert U.rel_l2(O[:, :3].float().cpu(), ref[:, :3]) < 3e-3      # the first queries see 1-3 keys only
+
+
 def test_flash_attention_forced_rescale(lib):
     """online-softmax rescale branch: one key row spikes late in the sequence (guide §5.4 rule 26)"""
     n, heads, Nq, Nk, C = 1, 1, 64, 256, 64
