@@ -9,13 +9,22 @@ Same argument meaning and error behaviour as the reference: input_ids [B, 77] in
 slots that would run past the sequence raise IndexError.  There is no CPU fallback.
 """
 import ctypes
-from types import SimpleNamespace
-
 import torch
 
 from . import _lib
 from ._lib import NativeError, TextConfig, check, ptr, stream_ptr
 from .modules import _Weights
+
+
+class TextEncoderOutput:
+    """the fields of transformers' BaseModelOutputWithPooling the reference touches; also indexable like it ([0] = last_hidden_state,
+    as in `self.text_encoder(ids, attention_mask=None)[0]`, tryon_pipe.py:249-253,297-301)"""
+
+    def __init__(self, last_hidden_state, pooler_output):
+        self.last_hidden_state, self.pooler_output, self.hidden_states, self.attentions = last_hidden_state, pooler_output, None, None
+
+    def __getitem__(self, i):
+        return (self.last_hidden_state, self.pooler_output)[i]
 
 
 class NativeCLIPTextEncoder:
@@ -40,7 +49,9 @@ class NativeCLIPTextEncoder:
             self.lib.ladi_text_encoder_destroy(self.h)
             self.h = None
 
-    def __call__(self, input_ids, word_embeddings=None, num_vstar=1):
+    def __call__(self, input_ids, word_embeddings=None, num_vstar=1, attention_mask=None):
+        if attention_mask is not None:
+            raise ValueError("attention_mask is not supported (the SD2 text encoder config has no use_attention_mask: tryon_pipe.py:244-247 passes None)")
         ids = input_ids.reshape(-1, input_ids.shape[-1]).to(device="cpu", dtype=torch.int32).contiguous()
         B, T = ids.shape
         H = self.cfg["hidden"]
@@ -61,7 +72,7 @@ class NativeCLIPTextEncoder:
         pooled = torch.empty((B, H), dtype=torch.float16, device=self.device)
         check(self.lib.ladi_text_encoder_forward(self.h, ctypes.c_void_p(ids.data_ptr()), B, T, ptr(we) if we is not None else None, num_vstar,
                                                  ptr(hidden), ptr(pooled), stream_ptr()), "ladi_text_encoder_forward")
-        return SimpleNamespace(last_hidden_state=hidden, pooler_output=pooled, hidden_states=None, attentions=None)
+        return TextEncoderOutput(hidden, pooled)
 
 
 def encode_text_word_embedding(text_encoder, input_ids, word_embeddings, num_vstar=1):
