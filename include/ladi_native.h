@@ -178,8 +178,9 @@ int ladi_tryon_stage_ms(ladi_tryon* t, float* out3);
 int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* avg_ms, void* stream);
 
 /* per-launch HIP-event timing of the implicit-GEMM kernel family (the dominant kernel): enable, run any entry point,
- * then collect: out[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP = 2*P*Q*K, launches}, cfg 1..6 = tile shapes
- * (Q128xP256, Q320xP128, Q128xP128, Q128xP64, Q64xP64, Q256xP128), index 0 = all; n_out >= 21. collect() synchronises and clears the records. */
+ * then collect: out[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP = 2*P*Q*K, launches} for tile configuration cfg = 1..31
+ * (igemm tile shapes, split-K variants, the X-stationary linear kernel; table in csrc/igemm.hip), index 0 = all; entries beyond
+ * n_out are dropped. collect() synchronises and clears the records. */
 /* measured tile-shape selection (default on): the first launch of a new problem shape outside a stream capture times the
  * admissible tile configurations and caches the fastest; off = static cost model */
 void ladi_igemm_set_autotune(int on);

@@ -18,6 +18,7 @@
 //   * the LDS image of a DMA is lane-linear (M0 base + lane*16 B), so the bank-conflict XOR swizzle is applied to the
 //     per-lane SOURCE address and again on the ds_read_b128 side (cdna_hip_programming.md §5.4 rule 21).
 //   * NST-stage LDS ring, one raw s_barrier per K step, counted vmcnt so that up to NST-1 stages stay in flight.
+//   * K-loop order: channel chunk outer, tap inner, so the taps of a 3x3 window re-use input rows from L2.
 //   * workgroup -> tile mapping is XCD-aware (block b runs on XCD b%8): each XCD walks a contiguous range of pixel
 //     (or channel) tiles so co-resident workgroups share operand panels in that XCD's private L2.
 #include "common.h"
@@ -451,7 +452,8 @@ bool ensure_ws(size_t bytes, hipStream_t st) {
 }
 
 struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; int base; int split; };
-// cfg 1..6 (0 = auto)
+// tile configurations (0 = choose: measured per shape when autotuning is on, else the cost model below).
+// {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K}
 constexpr int NCFG = 31;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1},
@@ -461,7 +463,7 @@ const CfgInfo kCfg[NCFG + 1] = {
     {128, 64, 4, true, 0.80f, 1, 4, 1},    // 4: <2,2,2,1> BK32 NST3
     {64, 64, 6, false, 0.60f, 1, 5, 1},    // 5: <2,2,1,1> BK32 NST3
     {256, 128, 2, true, 0.85f, 2, 6, 1},   // 6: <2,2,4,2> BK32 NST3
-    {128, 128, 2, true, 0.00f, 2, 7, 1},   // 7: <2,2,2,2> BK64 NST2   (eff 0: experimental, never auto-selected)
+    {128, 128, 2, true, 0.00f, 2, 7, 1},   // 7: <2,2,2,2> BK64 NST2   (eff 0: picked by measurement only, not by the fallback cost model)
     {128, 256, 1, true, 0.00f, 4, 8, 1},   // 8: <2,2,2,4> BK64 NST2
     {128, 64, 2, true, 0.00f, 1, 9, 1},    // 9: <2,2,2,1> BK64 NST3
     {320, 128, 1, false, 0.00f, 2, 10, 1},  // 10: <2,2,5,2> BK64 NST2
