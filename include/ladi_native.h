@@ -132,6 +132,23 @@ int ladi_text_encoder_forward(ladi_text_encoder* t, const int* input_ids_host, i
                               int num_vstar, void* out_hidden_dev, void* out_pooled_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * CLIP ViT-H/14 vision encoder — replaces the transformers CLIPVisionModelWithProjection forward the reference calls at
+ * src/inference.py:269-273 (`vision_encoder(pixel_values).last_hidden_state`, fed to the inversion adapter at :276).
+ * SURVEY.md §8(f) rank 2.  32 layers, 1280-d, 16 heads of 80, gelu MLP 5120, 224x224 / patch 14 -> 257 tokens.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct { int hidden, heads, mlp_dim, layers, image_size, patch_size; float layer_norm_eps; } ladi_vision_config;
+typedef struct ladi_vision_encoder ladi_vision_encoder;
+/* weights: transformers-4.27 key layout (vision_model.embeddings.*, vision_model.pre_layrnorm.*, vision_model.encoder.layers.N.*,
+ * vision_model.post_layernorm.*); the flattened layout without the vision_model. prefix is accepted too; visual_projection unused */
+ladi_vision_encoder* ladi_vision_encoder_create(const ladi_vision_config* cfg, const ladi_weights* ws);
+void ladi_vision_encoder_destroy(ladi_vision_encoder* v);
+/* pixel_values_dev: [B,3,S,S] (dtype: 0 fp32, 1 fp16), already CLIP-normalised (the CLIPProcessor stays on the caller's side);
+ * out_hidden_dev: fp16 [B][1 + (S/ps)^2][hidden] = last_hidden_state (encoder output, NO post_layernorm);
+ * out_pooled_dev: fp16 [B][hidden] = post_layernorm(last_hidden_state[:, 0]) (pooler_output) or NULL */
+int ladi_vision_encoder_forward(ladi_vision_encoder* v, const void* pixel_values_dev, int dtype, int B, void* out_hidden_dev,
+                                void* out_pooled_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Scheduler — replaces diffusers DDIMScheduler / PNDMScheduler (skip_prk_steps) set_timesteps + step
  * (tryon_pipe.py:650-651,740).  kind: 0 = DDIM, 1 = PNDM.
  * ------------------------------------------------------------------------------------------------------------- */
@@ -207,6 +224,10 @@ int ladi_op_attention(const void* q, const void* k, const void* v, void* o, int 
 int ladi_op_attention_causal(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq,
                              long long sk, long long sv, long long so, int n, int heads, int Nq, int Nk, float scale, int causal,
                              void* stream);
+/* heads of dimension head_dim in {64, 80, 96, 128} at column offset h*head_dim (ViT-H: 80) */
+int ladi_op_attention_generic(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq,
+                              long long sk, long long sv, long long so, int n, int heads, int head_dim, int Nq, int Nk, float scale,
+                              void* stream);
 int ladi_op_softmax_rows(const float* S, int rows, int cols, float scale, void* P, void* stream);
 int ladi_op_small_linear(const void* x, int x_f32, int ldx, const void* W, const void* bias, const void* res, int ldr, int M, int N,
                          int K, int act, int pre_silu, void* out, int out_f32, int ldo, void* stream);

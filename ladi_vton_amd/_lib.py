@@ -43,6 +43,11 @@ class TextConfig(Structure):
                 ("vstar_token_id", c_int), ("layer_norm_eps", c_float)]
 
 
+class VisionConfig(Structure):
+    _fields_ = [("hidden", c_int), ("heads", c_int), ("mlp_dim", c_int), ("layers", c_int), ("image_size", c_int), ("patch_size", c_int),
+                ("layer_norm_eps", c_float)]
+
+
 class TryOnInputs(Structure):
     _fields_ = [("batch", c_int), ("height", c_int), ("width", c_int), ("in_dtype", c_int),
                 ("image_dev", c_void_p), ("mask_image_dev", c_void_p), ("pose_map_dev", c_void_p), ("warped_cloth_dev", c_void_p),
@@ -91,6 +96,9 @@ SIGNATURES = {
     "ladi_adapter_create": (_P, [POINTER(AdapterConfig), _P]),
     "ladi_adapter_destroy": (None, [_P]),
     "ladi_adapter_forward": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "ladi_vision_encoder_create": (_P, [POINTER(VisionConfig), _P]),
+    "ladi_vision_encoder_destroy": (None, [_P]),
+    "ladi_vision_encoder_forward": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
     "ladi_text_encoder_create": (_P, [POINTER(TextConfig), _P]),
     "ladi_text_encoder_destroy": (None, [_P]),
     "ladi_text_encoder_forward": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P, _P, _P]),
@@ -110,6 +118,8 @@ SIGNATURES = {
                                   c_int, c_int, c_int, c_int, c_float, _P]),
     "ladi_op_attention_causal": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,
                                          c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "ladi_op_attention_generic": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,
+                                          c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "ladi_op_softmax_rows": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
     "ladi_op_small_linear": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "ladi_op_nchw_to_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),

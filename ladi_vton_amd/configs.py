@@ -167,6 +167,32 @@ def emasc_shapes(cfg):
     return sd
 
 
+# CLIP ViT-H/14 vision tower of laion/CLIP-ViT-H-14-laion2B-s32B-b79K: feeds the inversion adapter
+VISION_FULL = dict(hidden=1280, heads=16, mlp_dim=5120, layers=32, image_size=224, patch_size=14, layer_norm_eps=1e-5)
+VISION_TINY = dict(hidden=320, heads=4, mlp_dim=640, layers=2, image_size=56, patch_size=14, layer_norm_eps=1e-5)
+
+
+def vision_shapes(cfg):
+    """transformers 4.27 CLIPVisionModel(WithProjection) key layout: vision_model.* (visual_projection is not on the path)"""
+    sd = OrderedDict()
+    h, ps = cfg["hidden"], cfg["patch_size"]
+    ntok = (cfg["image_size"] // ps) ** 2 + 1
+    sd["vision_model.embeddings.class_embedding"] = (h,)
+    sd["vision_model.embeddings.patch_embedding.weight"] = (h, 3, ps, ps)
+    sd["vision_model.embeddings.position_embedding.weight"] = (ntok, h)
+    _norm(sd, "vision_model.pre_layrnorm", h)
+    for i in range(cfg["layers"]):
+        e = "vision_model.encoder.layers.%d" % i
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            _lin(sd, e + ".self_attn." + n, h, h)
+        _norm(sd, e + ".layer_norm1", h)
+        _lin(sd, e + ".mlp.fc1", h, cfg["mlp_dim"])
+        _lin(sd, e + ".mlp.fc2", cfg["mlp_dim"], h)
+        _norm(sd, e + ".layer_norm2", h)
+    _norm(sd, "vision_model.post_layernorm", h)
+    return sd
+
+
 def text_shapes(cfg):
     """transformers 4.27 CLIPTextModel key layout (the layout of the released text_encoder checkpoint): text_model.*"""
     sd = OrderedDict()

@@ -253,6 +253,147 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
     }
 }
 
+// Generic-head-dim attention (HD a multiple of 16, <= 128) for the CLIP ViT-H/14 vision tower (16 heads of d = 80, 257 tokens, once per
+// batch).  One wave per 32 queries; the same swapped product / lane-local online softmax / P-as-B-operand scheme as flash_attn64, but with
+// plain register staging of 64-key tiles (no DMA ring, no deferred-rescale threshold games beyond the shared reference trick): the
+// problem is tiny, simplicity wins.  O^T rows beyond HD (HD = 80 -> 96 rows of V^T) stay zero and are never stored.
+template <int HD>
+__global__ __launch_bounds__(64) void attn_generic_kernel(const AttnArgs a) {
+    constexpr int DK = HD / 16;              // k16 steps of S^T = K Q^T
+    constexpr int DB = (HD + 31) / 32;       // 32-row blocks of O^T
+    constexpr int KLD = HD + 8;              // halves per sK row (rows stay 16-byte aligned; 176 B stride is conflict-free for b128 reads)
+    constexpr int VLD = 64 + 4;              // halves per sVt row
+    __shared__ __attribute__((aligned(16))) h16 sK[64 * KLD];
+    __shared__ __attribute__((aligned(16))) h16 sVt[DB * 32 * VLD];
+    const int lane = threadIdx.x, l31 = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.y, n = blockIdx.z, qbase = blockIdx.x * 32;
+    const h16* __restrict__ qp = a.q + (size_t)n * a.sq + head * HD;
+    const h16* __restrict__ kp = a.k + (size_t)n * a.sk + head * HD;
+    const h16* __restrict__ vp = a.v + (size_t)n * a.sv + head * HD;
+    const float qscale = a.scale * 1.4426950408889634f;
+    h16x8 qf[DK];
+    {
+        const int qrow = qbase + l31;
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) {
+            h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qrow < a.Nq) v = *reinterpret_cast<const h16x8*>(qp + (size_t)qrow * a.ldq + ks * 16 + hh * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] * qscale);
+            qf[ks] = v;
+        }
+    }
+    f32x16 o_acc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+    for (int i = lane; i < DB * 32 * VLD; i += 64) sVt[i] = (h16)0.f;   // rows >= HD stay zero for the whole kernel
+
+    for (int key0 = 0; key0 < a.Nk; key0 += 64) {
+        __syncthreads();   // previous tile consumed
+        {
+            const int key = key0 + lane;
+            const bool valid = key < a.Nk;
+#pragma unroll
+            for (int c = 0; c < HD / 8; ++c) {
+                h16x8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (valid) {
+                    kk = *reinterpret_cast<const h16x8*>(kp + (size_t)key * a.ldk + c * 8);
+                    vv = *reinterpret_cast<const h16x8*>(vp + (size_t)key * a.ldv + c * 8);
+                }
+                *reinterpret_cast<h16x8*>(sK + lane * KLD + c * 8) = kk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sVt[(c * 8 + e) * VLD + lane] = vv[e];
+            }
+        }
+        __syncthreads();
+        const bool first = key0 == 0;
+        f32x16 s_acc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float init = -m_run;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_acc[kb][r] = init;
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) {
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(sK + (kb * 32 + l31) * KLD + ks * 16 + hh * 8);
+                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s_acc[kb], 0, 0, 0);
+            }
+        }
+        float mt = -1.0e30f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float sv = (key < a.Nk) ? s_acc[kb][r] : -1.0e30f;
+                s_acc[kb][r] = sv;
+                mt = fmaxf(mt, sv);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        if (first || __any(mt > RESCALE_THR)) {
+            const float delta = first ? mt : fmaxf(mt, 0.f);
+            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_acc[kb][r] -= delta;
+        }
+        float psum = 0.f;
+        h16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s_acc[kb][r]);
+                psum += p;
+                pf[kb][r >> 3][r & 7] = (h16)p;
+            }
+        l_run += psum;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int kofs = kb * 32 + k2 * 16 + 4 * hh;
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const h16* vrow = sVt + (d * 32 + l31) * VLD + kofs;
+                    const h16x4 lo = *reinterpret_cast<const h16x4*>(vrow);
+                    const h16x4 hi = *reinterpret_cast<const h16x4*>(vrow + 8);
+                    h16x8 vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][k2], o_acc[d], 0, 0, 0);
+                }
+            }
+    }
+    const float inv = 1.f / (l_run + __shfl_xor(l_run, 32));
+    const int qrow = qbase + l31;
+    if (qrow < a.Nq) {
+        h16* op = a.o + (size_t)n * a.so + (size_t)qrow * a.ldo + head * HD;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dc = d * 32 + 8 * g + 4 * hh;
+                if (dc < HD) {
+                    h16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (h16)(o_acc[d][4 * g + e] * inv);
+                    *reinterpret_cast<h16x4*>(op + dc) = o;
+                }
+            }
+    }
+}
+
 // One wave per (sample, head): a single query row against Nk keys; head dim d <= 128 (lanes own d and d+64).
 __global__ __launch_bounds__(64) void attn_single_query_kernel(const h16* __restrict__ q, int ldq, const h16* __restrict__ k,
                                                                int ldk, const h16* __restrict__ v, int ldv,
@@ -307,6 +448,19 @@ int ladi_launch_flash_attn64(const AttnArgs& a, hipStream_t st) {
     } else {
         b.qtiles = (a.Nq + 127) / 128;
         hipLaunchKernelGGL(flash_attn64_kernel<1>, dim3((unsigned)(b.qtiles * a.heads * a.n)), dim3(256), 0, st, b);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+int ladi_launch_attn_generic(const AttnArgs& a, int head_dim, hipStream_t st) {
+    if ((a.ldq & 7) || (a.ldk & 7) || (a.ldv & 7) || (a.ldo & 3) || a.Nk <= 0 || a.Nq <= 0 || a.causal) return -1;
+    dim3 grid((unsigned)((a.Nq + 31) / 32), (unsigned)a.heads, (unsigned)a.n);
+    switch (head_dim) {
+        case 64: hipLaunchKernelGGL(attn_generic_kernel<64>, grid, dim3(64), 0, st, a); break;
+        case 80: hipLaunchKernelGGL(attn_generic_kernel<80>, grid, dim3(64), 0, st, a); break;
+        case 96: hipLaunchKernelGGL(attn_generic_kernel<96>, grid, dim3(64), 0, st, a); break;
+        case 128: hipLaunchKernelGGL(attn_generic_kernel<128>, grid, dim3(64), 0, st, a); break;
+        default: return -2;
     }
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }

@@ -15,6 +15,7 @@ struct ladi_vae { VAE v; };
 struct ladi_emasc { EMASC e; };
 struct ladi_adapter { Adapter a; };
 struct ladi_text_encoder { TextEncoder t; };
+struct ladi_vision_encoder { VisionEncoder v; };
 struct ladi_tryon { TryOn t; };
 
 static_assert(sizeof(ladi_igemm_desc) == sizeof(IGemmArgs), "public igemm descriptor must mirror IGemmArgs");
@@ -335,6 +336,31 @@ int ladi_text_encoder_forward(ladi_text_encoder* t, const int* ids, int B, int T
     });
 }
 
+// ------------------------------------------------------------------------------------------------ vision encoder
+ladi_vision_encoder* ladi_vision_encoder_create(const ladi_vision_config* cfg, const ladi_weights* ws) {
+    ladi_vision_encoder* h = nullptr;
+    int rc = guarded("ladi_vision_encoder_create", [&]() {
+        if (!cfg || !ws) throw std::runtime_error("null argument");
+        require_gpu();
+        VisionCfg c; c.hidden = cfg->hidden; c.heads = cfg->heads; c.mlp = cfg->mlp_dim; c.layers = cfg->layers; c.image = cfg->image_size;
+        c.patch = cfg->patch_size; c.ln_eps = cfg->layer_norm_eps;
+        if (c.layers <= 0 || c.heads <= 0 || c.patch <= 0 || c.hidden % 32 || c.mlp % 32) throw std::runtime_error("vision encoder: bad config");
+        h = new ladi_vision_encoder();
+        h->v.load(c, ws->ws);
+        return 0;
+    });
+    if (rc) { delete h; return nullptr; }
+    return h;
+}
+void ladi_vision_encoder_destroy(ladi_vision_encoder* v) { delete v; }
+int ladi_vision_encoder_forward(ladi_vision_encoder* v, const void* px, int dtype, int B, void* out_hidden, void* out_pooled, void* stream) {
+    return guarded("ladi_vision_encoder_forward", [&]() {
+        if (!v || !px || !out_hidden) throw std::runtime_error("null argument");
+        if (dtype != 0 && dtype != 1) throw std::runtime_error("pixel_values dtype must be fp32 (0) or fp16 (1)");
+        return v->v.forward(px, dtype == 0, B, reinterpret_cast<h16*>(out_hidden), reinterpret_cast<h16*>(out_pooled), S(stream));
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ scheduler helpers
 int ladi_sched_timesteps(int kind, int steps, int* out, int cap) {
     return guarded("ladi_sched_timesteps", [&]() {
@@ -437,6 +463,15 @@ int ladi_op_attention_causal(const void* q, const void* k, const void* v, void* 
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.sq = sq; a.sk = sk; a.sv = sv; a.so = so;
     a.n = n; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale; a.causal = causal ? 1 : 0;
     return ladi_launch_flash_attn64(a, S(stream));
+}
+int ladi_op_attention_generic(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq,
+                              long long sk, long long sv, long long so, int n, int heads, int head_dim, int Nq, int Nk, float scale,
+                              void* stream) {
+    AttnArgs a;
+    a.q = (const h16*)q; a.k = (const h16*)k; a.v = (const h16*)v; a.o = (h16*)o;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.sq = sq; a.sk = sk; a.sv = sv; a.so = so;
+    a.n = n; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    return ladi_launch_attn_generic(a, head_dim, S(stream));
 }
 int ladi_op_softmax_rows(const float* Sm, int rows, int cols, float scale, void* P, void* stream) {
     return ladi_launch_softmax_rows(Sm, rows, cols, scale, (h16*)P, S(stream));

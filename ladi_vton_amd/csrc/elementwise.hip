@@ -447,6 +447,31 @@ __global__ void gather_rows_kernel(const h16* __restrict__ src, const int* __res
     for (int c = threadIdx.x; c < H; c += blockDim.x) dst[(size_t)blockIdx.x * H + c] = s[c];
 }
 
+// ViT patch extraction for the bias-free patch-embedding conv (kernel = stride = ps): rows [B][1 + G*G][KP], row 0 (class-token slot)
+// and columns >= 3*ps*ps zero; column c*ps*ps + ky*ps + kx = pixel[b][c][gy*ps + ky][gx*ps + kx] (the flatten order of the conv weight)
+__global__ void patchify_kernel(const void* __restrict__ px, int in_f32, int S, int ps, int G, int KP, h16* __restrict__ out) {
+    const int T = 1 + G * G;
+    const int row = blockIdx.x, b = row / T, t = row - b * T;
+    h16* o = out + (size_t)row * KP;
+    const int nk = 3 * ps * ps;
+    for (int k = threadIdx.x; k < KP; k += blockDim.x) {
+        float v = 0.f;
+        if (t > 0 && k < nk) {
+            const int c = k / (ps * ps), r = k - c * ps * ps, ky = r / ps, kx = r - ky * ps;
+            const int gy = (t - 1) / G, gx = (t - 1) - gy * G;
+            const size_t idx = (((size_t)b * 3 + c) * S + (gy * ps + ky)) * S + gx * ps + kx;
+            v = in_f32 ? reinterpret_cast<const float*>(px)[idx] : (float)reinterpret_cast<const h16*>(px)[idx];
+        }
+        o[k] = (h16)v;
+    }
+}
+int ladi_launch_patchify(const void* px, int in_f32, int B, int S, int ps, int KP, h16* out, hipStream_t st) {
+    if (ps <= 0 || S % ps || KP < 3 * ps * ps) return -1;
+    const int G = S / ps;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)(B * (1 + G * G))), dim3(256), 0, st, px, in_f32, S, ps, G, KP, out);
+    return ok();
+}
+
 int ladi_launch_text_embed(const int* ids, const int* first, int nv, const h16* tok, const h16* pos, const h16* wemb, int B, int T,
                            int H, h16* out, hipStream_t st) {
     if (H % 8) return -1;

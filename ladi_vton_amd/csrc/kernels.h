@@ -39,6 +39,8 @@ struct AttnArgs {
     int qtiles = 0, xcd_map = 0;            // set by the launcher: query tiles per (sample, head); XCD-aware workgroup order
 };
 int ladi_launch_flash_attn64(const AttnArgs& a, hipStream_t st);
+// heads of dimension 64 / 80 / 96 / 128 at column offset h*head_dim (CLIP ViT-H vision tower: 80); non-causal
+int ladi_launch_attn_generic(const AttnArgs& a, int head_dim, hipStream_t st);
 // single query per (sample, head): q [n][ldq], k/v [n][Nk][ld], generic head dim d <= 128
 int ladi_launch_attn_single_query(const h16* q, int ldq, const h16* k, int ldk, const h16* v, int ldv, h16* o, int ldo,
                                   int n, int heads, int d, int Nk, long long sk, long long sv, float scale, hipStream_t st);
@@ -100,6 +102,8 @@ int ladi_launch_fill_f32(float* p, size_t n, float v, hipStream_t st);
 // wemb fp16 [B][nv][H] or null; out [B][T][H] = (token | pseudo-word) embedding + position embedding
 int ladi_launch_text_embed(const int* ids, const int* first, int nv, const h16* tok, const h16* pos, const h16* wemb, int B, int T,
                            int H, h16* out, hipStream_t st);
+// ViT patch rows for the patch-embedding GEMM: out [B][1 + (S/ps)^2][KP] fp16, row 0 and the padding columns zero
+int ladi_launch_patchify(const void* px, int in_f32, int B, int S, int ps, int KP, h16* out, hipStream_t st);
 int ladi_launch_gather_rows(const h16* src, const int* rows, int n, int H, h16* dst, hipStream_t st);
 // decoder input: post_quant_conv(lat / scaling_factor) -> NHWC fp16 padded to ld; pq = device [16 w | 4 b] or null (identity)
 int ladi_launch_post_quant(const float* lat, const float* pq, float inv_sf, int n, h16* dst, int ld, hipStream_t st);

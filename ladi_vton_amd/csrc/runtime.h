@@ -210,6 +210,21 @@ struct TextEncoder {
     ~TextEncoder();
 };
 
+// CLIP ViT-H/14 vision encoder (the `vision_encoder(pixel_values).last_hidden_state` of src/inference.py:269-273)
+struct VisionCfg { int hidden = 1280, heads = 16, mlp = 5120, layers = 32, image = 224, patch = 14; float ln_eps = 1e-5f; };
+struct VisionEncoder {
+    VisionCfg cfg; DevPool pool;
+    DConv patch;                 // [hidden][3*ps*ps padded to 64] bias-free
+    h16* posc = nullptr;         // [tokens][hidden]: position embedding, class embedding added to row 0
+    DNorm pre_ln, post_ln; std::vector<TextLayer> layers;
+    Arena arena;
+    int tokens() const { return 1 + (cfg.image / cfg.patch) * (cfg.image / cfg.patch); }
+    void load(const VisionCfg& c, const WeightStore& ws);
+    // pixels [B][3][image][image] (fp32 or fp16, device); out_hidden fp16 [B][tokens][hidden] (encoder output, no post_layernorm);
+    // out_pooled fp16 [B][hidden] = post_layernorm(out_hidden[:, 0]) or null
+    int forward(const void* pixels, int in_f32, int B, h16* out_hidden, h16* out_pooled, hipStream_t st);
+};
+
 struct TryOnInputs {
     int batch, height, width, in_f32;
     const void *image, *mask_image, *pose_map, *warped_cloth;

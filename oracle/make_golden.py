@@ -68,6 +68,7 @@ def main():
     save_file({"x": x, "y": y.contiguous()}, os.path.join(OUT, "clip_encoder_layer_tiny.safetensors"))
 
     make_text_golden(g)
+    make_vision_golden(g)
     print("wrote", os.listdir(OUT))
 
 
@@ -99,6 +100,32 @@ class _TextModel42:
     def encoder(self, inputs_embeds, attention_mask, causal_attention_mask, output_attentions, output_hidden_states, return_dict):
         out = self.m.encoder(inputs_embeds=inputs_embeds, attention_mask=causal_attention_mask, is_causal=True)
         return _Out42((out.last_hidden_state,))
+
+
+def make_vision_golden(g):
+    """tests/golden/clip_vision_tiny.safetensors: installed transformers CLIPVisionModel (the class behind inference.py:269-273's
+    vision_encoder) with the deterministic tiny checkpoint: last_hidden_state (what the adapter consumes) and pooler_output"""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from ladi_vton_amd import configs as C
+    vc = C.VISION_TINY
+    hc = CLIPVisionConfig(hidden_size=vc["hidden"], intermediate_size=vc["mlp_dim"], num_hidden_layers=vc["layers"],
+                          num_attention_heads=vc["heads"], image_size=vc["image_size"], patch_size=vc["patch_size"], hidden_act="gelu",
+                          layer_norm_eps=vc["layer_norm_eps"], attention_dropout=0.0)
+    try:
+        hc._attn_implementation = "eager"
+    except Exception:
+        pass
+    m = CLIPVisionModel(hc).eval()
+    sd = C.synth_state_dict(C.vision_shapes(vc), "vision.")
+    own = m.state_dict()
+    flat = {(k[len("vision_model."):] if k[len("vision_model."):] in own else k): v for k, v in sd.items()}
+    missing, unexpected = m.load_state_dict(flat, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    x = (torch.randn((3, 3, vc["image_size"], vc["image_size"]), generator=g) * 1.2).half().float()   # CLIP-normalised pixel range
+    with torch.no_grad():
+        out = m(pixel_values=x)
+    save_file({"pixel_values": x, "last_hidden_state": out.last_hidden_state.contiguous(), "pooler_output": out.pooler_output.contiguous()},
+              os.path.join(OUT, "clip_vision_tiny.safetensors"))
 
 
 def make_text_golden(g):

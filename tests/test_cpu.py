@@ -92,6 +92,17 @@ def test_text_oracle_matches_reference_golden():
         T.splice_word_embeddings(emb, bad, we, 3)
 
 
+def test_vision_oracle_matches_transformers_golden():
+    """fixture = installed transformers CLIPVisionModel (the third-party class behind src/inference.py:269-273) on the tiny checkpoint"""
+    from oracle import vision as V
+    c = load_file(os.path.join(GOLD, "clip_vision_tiny.safetensors"))
+    sd = C.synth_state_dict(C.vision_shapes(C.VISION_TINY), "vision.")
+    hs, pooled = V.clip_vision_forward(sd, C.VISION_TINY, c["pixel_values"])
+    assert torch.allclose(hs, c["last_hidden_state"], atol=5e-5, rtol=1e-5)
+    assert torch.allclose(pooled, c["pooler_output"], atol=5e-5, rtol=1e-5)
+    assert C.param_count(C.vision_shapes(C.VISION_FULL)) == 630_766_080     # ViT-H/14 vision tower without the 1280x1024 projection
+
+
 def test_mask_features_progressive_equals_strided():
     """SURVEY.md §3.3: the progressive nearest chain equals mask[..., ::s, ::s] (what the native kernels implement)"""
     g = torch.Generator().manual_seed(0)

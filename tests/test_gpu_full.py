@@ -94,3 +94,26 @@ def test_full_text_encoder_vs_oracle():
     got, pooled = out.last_hidden_state.float().cpu(), out.pooler_output.float().cpu()
     assert U.psnr(got, ref) >= 45.0 and U.rel_l2(got, ref) <= 1e-2, (U.psnr(got, ref), U.rel_l2(got, ref))
     assert U.rel_l2(pooled, ref_pooled) <= 1e-2
+
+
+def test_full_vision_encoder_feeds_adapter_vs_oracle():
+    """ViT-H/14 size (32 layers, 1280-d, 16 heads of 80, 257 tokens, 630.8 M parameters) -> inversion adapter (inference.py:269-277)"""
+    import ladi_vton_amd as L
+    from oracle import vision as V
+    cfg = C.VISION_FULL
+    sd = C.synth_state_dict(C.vision_shapes(cfg), "vision.")
+    enc = L.NativeCLIPVisionEncoder(cfg, sd)
+    px = (torch.randn((2, 3, 224, 224), generator=torch.Generator().manual_seed(31)) * 1.2).half().float()
+    ref, ref_pooled = V.clip_vision_forward(sd, cfg, px)
+    out = enc(px.to(U.dev()))
+    torch.cuda.synchronize()
+    got = out.last_hidden_state.float().cpu()
+    assert got.shape == (2, 257, 1280)
+    assert U.psnr(got, ref) >= 40.0 and U.rel_l2(got, ref) <= 2e-2, (U.psnr(got, ref), U.rel_l2(got, ref))
+    assert U.rel_l2(out.pooler_output.float().cpu(), ref_pooled) <= 2e-2
+    acfg = C.ADAPTER_FULL
+    asd = C.synth_state_dict(C.adapter_shapes(acfg), "adapter.")
+    ad = L.NativeInversionAdapter(acfg, asd)
+    we = ad(out.last_hidden_state).float().cpu()
+    we_ref = M.adapter_forward(asd, acfg, ref)
+    assert U.psnr(we, we_ref) >= 40.0, U.psnr(we, we_ref)

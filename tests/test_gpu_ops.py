@@ -282,6 +282,25 @@ def test_flash_attention_causal(lib, n, heads, T):
     assert U.rel_l2(O[:, :3].float().cpu(), ref[:, :3]) < 3e-3      # the first queries see 1-3 keys only
 
 
+@pytest.mark.parametrize("n,heads,hd,Nq,Nk", [(2, 2, 80, 257, 257), (1, 3, 80, 17, 17), (1, 2, 64, 100, 70), (1, 1, 128, 65, 129), (2, 1, 96, 33, 200)])
+def test_attention_generic_head_dim(lib, n, heads, hd, Nq, Nk):
+    """MFMA attention for head dims other than 64 (CLIP ViT-H vision tower: 16 heads of 80, 257 tokens); ragged query / key tiles"""
+    C = heads * hd
+    q, k, v = _rand((n, Nq, C), 250), _rand((n, Nk, C), 251), _rand((n, Nk, C), 252)
+    k[0, Nk - 1, :hd] = q[0, 3, :hd] * 4.0      # a late spike exercises the rescale branch
+    qh = q.view(n, Nq, heads, hd).transpose(1, 2)
+    kh = k.view(n, Nk, heads, hd).transpose(1, 2)
+    vh = v.view(n, Nk, heads, hd).transpose(1, 2)
+    sc = hd ** -0.5
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * sc, -1) @ vh).transpose(1, 2).reshape(n, Nq, C)
+    Q, K, V = q.half().to(U.dev()), k.half().to(U.dev()), v.half().to(U.dev())
+    O = torch.full((n, Nq, C), 7.0, dtype=torch.float16, device=U.dev())
+    rc = lib.ladi_op_attention_generic(ptr(Q), ptr(K), ptr(V), ptr(O), C, C, C, C, Nq * C, Nk * C, Nk * C, Nq * C, n, heads, hd, Nq, Nk, sc, stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert U.rel_l2(O.float().cpu(), ref) < 3e-3
+
+
 def test_flash_attention_forced_rescale(lib):
     """online-softmax rescale branch: one key row spikes late in the sequence (guide §5.4 rule 26)"""
     n, heads, Nq, Nk, C = 1, 1, 64, 256, 64
