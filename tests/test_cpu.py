@@ -225,6 +225,44 @@ def test_pipeline_check_inputs_errors():
         L.StableDiffusionTryOnePipeline._validate_images(torch.zeros(1, 3, 8, 8), torch.zeros(1, 1, 4, 8))
 
 
+def test_on_disk_formats_roundtrip_with_reference_readers(tmp_path):
+    """files written by ladi_vton_amd.io must be readable with the exact calls the reference uses (vitonhd.py:100-107,
+    inference.py:314-324) and vice versa"""
+    import pickle
+    from ladi_vton_amd import io as IO
+    from ladi_vton_amd.pipeline import numpy_to_pil
+    root = str(tmp_path)
+    feats = torch.randn((3, 257, 16))
+    names = ["00001_00.jpg", "00002_00.jpg", "00003_00.jpg"]
+    ft, nm = IO.save_clip_cloth_features(root, "vitonhd", "test", feats, names)
+    assert ft.endswith("data/clip_cloth_embeddings/vitonhd/test_last_hidden_state_features.pt") and nm.endswith("test_features_names.pkl")
+    raw = torch.load(ft, map_location="cpu")                       # the reference's reader
+    with open(nm, "rb") as f:
+        raw_names = pickle.load(f)
+    assert raw.dtype == torch.float16 and raw.shape == (3, 257, 16) and raw_names == names
+    got, got_names = IO.load_clip_cloth_features(root, "vitonhd", "test")
+    assert torch.equal(got, feats.half()) and got_names == names and not got.requires_grad
+    assert torch.equal(got[got_names.index("00002_00.jpg")], feats[1].half())
+    with pytest.raises(ValueError):
+        IO.save_clip_cloth_features(root, "vitonhd", "bad", feats, names[:2])
+    # checkpoints: plain state_dict and the {'tps', 'refinement'} container of the warping release
+    sd = {"conv.weight": torch.randn(2, 2), "conv.bias": torch.zeros(2)}
+    torch.save(sd, os.path.join(root, "emasc_vitonhd.pth"))
+    torch.save({"tps": sd, "refinement": sd}, os.path.join(root, "warping_vitonhd.pth"))
+    assert torch.equal(IO.load_released_state_dict(os.path.join(root, "emasc_vitonhd.pth"))["conv.weight"], sd["conv.weight"])
+    assert set(IO.load_released_state_dict(os.path.join(root, "warping_vitonhd.pth"), "tps")) == set(sd)
+    with pytest.raises(ValueError):
+        IO.load_released_state_dict(os.path.join(root, "warping_vitonhd.pth"))
+    # images: {save_dir}/{category}/{name}, JPEG q95 or PNG with the .jpg -> .png rename
+    from PIL import Image
+    imgs = numpy_to_pil(torch.rand((2, 16, 12, 3)).numpy())
+    paths = IO.save_generated_images(imgs, os.path.join(root, "out"), ["upper_body", "dresses"], ["a.jpg", "b.jpg"], use_png=False)
+    assert [os.path.relpath(p, root) for p in paths] == ["out/upper_body/a.jpg", "out/dresses/b.jpg"]
+    assert Image.open(paths[0]).format == "JPEG" and Image.open(paths[0]).size == (12, 16)
+    paths = IO.save_generated_images(imgs, os.path.join(root, "out"), ["upper_body", "dresses"], ["a.jpg", "b.jpg"], use_png=True)
+    assert paths[1].endswith("out/dresses/b.png") and Image.open(paths[1]).format == "PNG"
+
+
 def test_shard_bounds_cover_batch():
     from ladi_vton_amd.parallel import shard_bounds
     for B in (1, 7, 8, 32, 255, 256):
