@@ -220,8 +220,6 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void igemm_kernel(const IGemmArgs 
     const size_t zo = (size_t)z * a.bs_out;
     const size_t zr = (size_t)z * a.bs_res;
     const bool vec_ok = ((a.ldo & 3) == 0);
-    const bool rvec0 = a.res0 && ((a.ldr0 & 3) == 0);
-    const bool rvec1 = a.res1 && ((a.ldr1 & 3) == 0);
 
     // per-pixel quantities of this lane's TP pixel columns (compile-time indices: no scratch)
     int pj[TP]; bool prow[TP]; float pbj[TP];
