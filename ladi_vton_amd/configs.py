@@ -167,6 +167,65 @@ def emasc_shapes(cfg):
     return sd
 
 
+# warping module (hubconf.py:56-66): ConvNet_TPS(256, 192, input_nc=21, n_layer=3) + UNetVanilla(24, 3, bilinear=True)
+TPS_FULL = dict(height=256, width=192, input_nc=21, n_layers=3, grid=5, ngf=64)
+REFINE_FULL = dict(in_channels=24, out_channels=3, base=64)
+
+
+def _bn(sd, name, c):
+    for k in ("weight", "bias", "running_mean", "running_var"):
+        sd[name + "." + k] = (c,)
+
+
+def tps_shapes(cfg):
+    """state_dict layout of src/models/ConvNet_TPS.py ConvNet_TPS (nn.Sequential indices; num_batches_tracked and the TPSGridGen
+    buffers are derived, not parameters)"""
+    sd = OrderedDict()
+    ngf, nl = cfg["ngf"], cfg["n_layers"]
+
+    def extraction(prefix, cin):
+        i = 0
+        _conv(sd, "%s.model.%d" % (prefix, i), cin, ngf, 4); _bn(sd, "%s.model.%d" % (prefix, i + 2), ngf); i += 3
+        for l in range(nl):
+            a = min(2 ** l * ngf, 512)
+            b = 2 ** (l + 1) * ngf if 2 ** l * ngf < 512 else 512
+            _conv(sd, "%s.model.%d" % (prefix, i), a, b, 4); _bn(sd, "%s.model.%d" % (prefix, i + 2), b); i += 3
+        _conv(sd, "%s.model.%d" % (prefix, i), 512, 512, 3); _bn(sd, "%s.model.%d" % (prefix, i + 2), 512); i += 3
+        _conv(sd, "%s.model.%d" % (prefix, i), 512, 512, 3)
+
+    extraction("extractionA", 3)
+    extraction("extractionB", cfg["input_nc"])
+    r = "loc_net.regression.conv"
+    corr = (cfg["height"] // 16) * (cfg["width"] // 16)
+    for i, (a, b, k) in enumerate(((corr, 512, 4), (512, 256, 4), (256, 128, 3), (128, 64, 3))):
+        _conv(sd, "%s.%d" % (r, 3 * i), a, b, k); _bn(sd, "%s.%d" % (r, 3 * i + 1), b)
+    _lin(sd, "loc_net.regression.linear", 64 * (cfg["height"] // 64) * (cfg["width"] // 64), 2 * cfg["grid"] ** 2)
+    return sd
+
+
+def refine_shapes(cfg):
+    """state_dict layout of src/models/UNet.py UNetVanilla(bilinear=True) (src/models/unet_parts.py)"""
+    sd = OrderedDict()
+    b = cfg["base"]
+
+    def dconv(name, cin, cout, mid=None):
+        mid = mid or cout
+        sd[name + ".double_conv.0.weight"] = (mid, cin, 3, 3); _bn(sd, name + ".double_conv.1", mid)
+        sd[name + ".double_conv.3.weight"] = (cout, mid, 3, 3); _bn(sd, name + ".double_conv.4", cout)
+
+    dconv("inc", cfg["in_channels"], b)
+    dconv("down1.maxpool_conv.1", b, 2 * b)
+    dconv("down2.maxpool_conv.1", 2 * b, 4 * b)
+    dconv("down3.maxpool_conv.1", 4 * b, 8 * b)
+    dconv("down4.maxpool_conv.1", 8 * b, 8 * b)               # 1024 // 2 with bilinear upsampling
+    dconv("up1.conv", 16 * b, 4 * b, 8 * b)
+    dconv("up2.conv", 8 * b, 2 * b, 4 * b)
+    dconv("up3.conv", 4 * b, b, 2 * b)
+    dconv("up4.conv", 2 * b, b, b)
+    _conv(sd, "outc.conv", b, cfg["out_channels"], 1)
+    return sd
+
+
 # CLIP ViT-H/14 vision tower of laion/CLIP-ViT-H-14-laion2B-s32B-b79K (SURVEY.md App. A.0): feeds the inversion adapter
 VISION_FULL = dict(hidden=1280, heads=16, mlp_dim=5120, layers=32, image_size=224, patch_size=14, layer_norm_eps=1e-5)
 VISION_TINY = dict(hidden=320, heads=4, mlp_dim=640, layers=2, image_size=56, patch_size=14, layer_norm_eps=1e-5)
@@ -249,6 +308,10 @@ def _is_norm(key):
 def synth_tensor(key, shape, scope=""):
     g = torch.Generator().manual_seed(zlib.crc32((scope + key).encode()) & 0x7FFFFFFF)
     u = torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1
+    if key.endswith(".running_var"):
+        return 0.5 + torch.rand(shape, generator=g, dtype=torch.float32)
+    if key.endswith(".running_mean"):
+        return 0.1 * u
     if _is_norm(key):
         return 1.0 + 0.1 * u if key.endswith(".weight") else 0.1 * u
     if key.endswith(".weight"):

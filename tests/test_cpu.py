@@ -103,6 +103,33 @@ def test_vision_oracle_matches_transformers_golden():
     assert C.param_count(C.vision_shapes(C.VISION_FULL)) == 630_766_080     # ViT-H/14 vision tower without the 1280x1024 projection
 
 
+def test_warp_oracle_matches_reference_modules_golden():
+    """fixture = the REAL reference ConvNet_TPS sub-modules + UNetVanilla (oracle/make_golden.py) on the deterministic checkpoint;
+    inputs are regenerated from the seed, only outputs are stored"""
+    import warnings
+    from oracle import warp as W
+    from oracle.make_golden import warp_inputs
+    c = load_file(os.path.join(GOLD, "warp_modules.safetensors"))
+    tsd = C.synth_state_dict(C.tps_shapes(C.TPS_FULL), "tps.", fp16_round=False)
+    tsd["loc_net.regression.linear.weight"] = tsd["loc_net.regression.linear.weight"] * 0.2
+    rsd = C.synth_state_dict(C.refine_shapes(C.REFINE_FULL), "refine.", fp16_round=False)
+    cloth, agnostic, refine_in = warp_inputs()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fa = W.l2norm(W.feature_extraction(tsd, "extractionA", cloth, 3))
+        fb = W.l2norm(W.feature_extraction(tsd, "extractionB", agnostic, 3))
+        corr = W.correlation(fa, fb)
+        grid, coor = W.tps_forward(tsd, C.TPS_FULL, cloth, agnostic)
+        warped = W.warp(cloth, grid)
+        refined = W.refinement_forward(rsd, refine_in)
+    assert torch.allclose(corr[:, :, ::4, ::4], c["corr_sample"], atol=1e-5, rtol=1e-4)
+    assert torch.allclose(coor, c["coor"], atol=1e-5, rtol=1e-4) and coor.abs().max() < 0.999   # tanh not saturated: a real check
+    assert torch.allclose(grid, c["grid"].float(), atol=2e-3)                                  # fixture stored as fp16
+    assert torch.allclose(warped, c["warped"].float(), atol=5e-3)
+    assert torch.allclose(refined, c["refined"], atol=1e-4, rtol=1e-4)
+    assert grid.shape == (1, 256, 192, 2) and refined.shape == (1, 3, 64, 48)
+
+
 def test_mask_features_progressive_equals_strided():
     """SURVEY.md §3.3: the progressive nearest chain equals mask[..., ::s, ::s] (what the native kernels implement)"""
     g = torch.Generator().manual_seed(0)
