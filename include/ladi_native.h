@@ -149,6 +149,20 @@ int ladi_vision_encoder_forward(ladi_vision_encoder* v, const void* pixel_values
                                 void* out_pooled_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Refinement UNet of the warping module — replaces src/models/UNet.py UNetVanilla.forward (:23-34; parts in src/models/unet_parts.py)
+ * as instantiated by hubconf.py:57 (24 -> 3 channels, bilinear=True) and called at src/inference.py:264.  SURVEY.md §8(f) rank 3
+ * (first half; the TPS matching network is not native yet).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct { int in_channels, out_channels, base_channels; float bn_eps; } ladi_refine_config;
+typedef struct ladi_refine ladi_refine;
+/* weights: the 'refinement' state_dict of the released warping checkpoint (hubconf.py:62): inc.double_conv.*, downN.maxpool_conv.1.*,
+ * upN.conv.double_conv.*, outc.conv.*; BatchNorm running statistics are folded into the convolutions (inference mode) */
+ladi_refine* ladi_refine_create(const ladi_refine_config* cfg, const ladi_weights* ws);
+void ladi_refine_destroy(ladi_refine* r);
+/* x_dev: [B, in_channels, H, W] NCHW (dtype 0 fp32 / 1 fp16), H and W multiples of 16; out_dev: [B, out_channels, H, W] NCHW (out_dtype) */
+int ladi_refine_forward(ladi_refine* r, const void* x_dev, int dtype, int B, int H, int W, void* out_dev, int out_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Scheduler — replaces diffusers DDIMScheduler / PNDMScheduler (skip_prk_steps) set_timesteps + step
  * (tryon_pipe.py:650-651,740).  kind: 0 = DDIM, 1 = PNDM.
  * ------------------------------------------------------------------------------------------------------------- */
@@ -228,6 +242,9 @@ int ladi_op_attention_causal(const void* q, const void* k, const void* v, void* 
 int ladi_op_attention_generic(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq,
                               long long sk, long long sv, long long so, int n, int heads, int head_dim, int Nq, int Nk, float scale,
                               void* stream);
+/* NHWC fp16 helpers of the refinement UNet: 2x2 max pooling, bilinear x2 upsampling with align_corners=True (C % 8 == 0) */
+int ladi_op_maxpool2(const void* src, int n, int H, int W, int C, void* dst, void* stream);
+int ladi_op_upsample2x_bilinear(const void* src, int n, int H, int W, int C, void* dst, void* stream);
 int ladi_op_softmax_rows(const float* S, int rows, int cols, float scale, void* P, void* stream);
 int ladi_op_small_linear(const void* x, int x_f32, int ldx, const void* W, const void* bias, const void* res, int ldr, int M, int N,
                          int K, int act, int pre_silu, void* out, int out_f32, int ldo, void* stream);

@@ -48,6 +48,10 @@ class VisionConfig(Structure):
                 ("layer_norm_eps", c_float)]
 
 
+class RefineConfig(Structure):
+    _fields_ = [("in_channels", c_int), ("out_channels", c_int), ("base_channels", c_int), ("bn_eps", c_float)]
+
+
 class TryOnInputs(Structure):
     _fields_ = [("batch", c_int), ("height", c_int), ("width", c_int), ("in_dtype", c_int),
                 ("image_dev", c_void_p), ("mask_image_dev", c_void_p), ("pose_map_dev", c_void_p), ("warped_cloth_dev", c_void_p),
@@ -99,6 +103,9 @@ SIGNATURES = {
     "ladi_vision_encoder_create": (_P, [POINTER(VisionConfig), _P]),
     "ladi_vision_encoder_destroy": (None, [_P]),
     "ladi_vision_encoder_forward": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
+    "ladi_refine_create": (_P, [POINTER(RefineConfig), _P]),
+    "ladi_refine_destroy": (None, [_P]),
+    "ladi_refine_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "ladi_text_encoder_create": (_P, [POINTER(TextConfig), _P]),
     "ladi_text_encoder_destroy": (None, [_P]),
     "ladi_text_encoder_forward": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P, _P, _P]),
@@ -120,6 +127,8 @@ SIGNATURES = {
                                          c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "ladi_op_attention_generic": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,
                                           c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "ladi_op_maxpool2": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "ladi_op_upsample2x_bilinear": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "ladi_op_softmax_rows": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
     "ladi_op_small_linear": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "ladi_op_nchw_to_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),

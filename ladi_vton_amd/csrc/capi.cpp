@@ -16,6 +16,7 @@ struct ladi_emasc { EMASC e; };
 struct ladi_adapter { Adapter a; };
 struct ladi_text_encoder { TextEncoder t; };
 struct ladi_vision_encoder { VisionEncoder v; };
+struct ladi_refine { Refine r; };
 struct ladi_tryon { TryOn t; };
 
 static_assert(sizeof(ladi_igemm_desc) == sizeof(IGemmArgs), "public igemm descriptor must mirror IGemmArgs");
@@ -361,6 +362,29 @@ int ladi_vision_encoder_forward(ladi_vision_encoder* v, const void* px, int dtyp
     });
 }
 
+// ------------------------------------------------------------------------------------------------ refinement UNet
+ladi_refine* ladi_refine_create(const ladi_refine_config* cfg, const ladi_weights* ws) {
+    ladi_refine* h = nullptr;
+    int rc = guarded("ladi_refine_create", [&]() {
+        if (!cfg || !ws) throw std::runtime_error("null argument");
+        require_gpu();
+        RefineCfg c; c.in_ch = cfg->in_channels; c.out_ch = cfg->out_channels; c.base = cfg->base_channels; c.bn_eps = cfg->bn_eps;
+        h = new ladi_refine();
+        h->r.load(c, ws->ws);
+        return 0;
+    });
+    if (rc) { delete h; return nullptr; }
+    return h;
+}
+void ladi_refine_destroy(ladi_refine* r) { delete r; }
+int ladi_refine_forward(ladi_refine* r, const void* x, int dtype, int B, int H, int W, void* out, int out_dtype, void* stream) {
+    return guarded("ladi_refine_forward", [&]() {
+        if (!r || !x || !out) throw std::runtime_error("null argument");
+        if ((dtype != 0 && dtype != 1) || (out_dtype != 0 && out_dtype != 1)) throw std::runtime_error("dtype must be fp32 (0) or fp16 (1)");
+        return r->r.forward(x, dtype == 0, B, H, W, out, out_dtype == 0, S(stream));
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ scheduler helpers
 int ladi_sched_timesteps(int kind, int steps, int* out, int cap) {
     return guarded("ladi_sched_timesteps", [&]() {
@@ -472,6 +496,12 @@ int ladi_op_attention_generic(const void* q, const void* k, const void* v, void*
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.sq = sq; a.sk = sk; a.sv = sv; a.so = so;
     a.n = n; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     return ladi_launch_attn_generic(a, head_dim, S(stream));
+}
+int ladi_op_maxpool2(const void* src, int n, int H, int W, int C, void* dst, void* stream) {
+    return ladi_launch_maxpool2((const h16*)src, C, n, H, W, C, (h16*)dst, C, S(stream));
+}
+int ladi_op_upsample2x_bilinear(const void* src, int n, int H, int W, int C, void* dst, void* stream) {
+    return ladi_launch_upsample2x_bilinear_ac((const h16*)src, C, n, H, W, C, (h16*)dst, C, S(stream));
 }
 int ladi_op_softmax_rows(const float* Sm, int rows, int cols, float scale, void* P, void* stream) {
     return ladi_launch_softmax_rows(Sm, rows, cols, scale, (h16*)P, S(stream));

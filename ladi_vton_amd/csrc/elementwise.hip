@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const XT* __restrict_
             if (bias) s += (float)bias[nn];
             if (act == LADI_ACT_SILU) s = silu_f(s);
             else if (act == LADI_ACT_GELU) s = gelu_f(s);
+            else if (act == LADI_ACT_RELU) s = fmaxf(s, 0.f);
             if (res) s += (float)res[(size_t)m * ldr + nn];
             if (out_f32) reinterpret_cast<float*>(out)[(size_t)m * ldo + nn] = s;
             else reinterpret_cast<h16*>(out)[(size_t)m * ldo + nn] = (h16)s;
@@ -445,6 +446,63 @@ __global__ void text_embed_kernel(const int* __restrict__ ids, const int* __rest
 __global__ void gather_rows_kernel(const h16* __restrict__ src, const int* __restrict__ rows, int H, h16* __restrict__ dst) {
     const h16* s = src + (size_t)rows[blockIdx.x] * H;
     for (int c = threadIdx.x; c < H; c += blockDim.x) dst[(size_t)blockIdx.x * H + c] = s[c];
+}
+
+// 2x2 max pooling, NHWC fp16 (nn.MaxPool2d(2) of the refinement UNet, unet_parts.py:33-36); 8 channels per thread
+__global__ void maxpool2_kernel(const h16* __restrict__ src, int lds_, int n, int H, int W, int C, h16* __restrict__ dst, int ldd) {
+    const int Ho = H / 2, Wo = W / 2, oc = C / 8;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * Ho * Wo * oc) return;
+    const int c8 = (int)(idx % oc);
+    size_t p = idx / oc;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho); const int b = (int)(p / Ho);
+    const h16* s0 = src + (((size_t)b * H + 2 * oy) * W + 2 * ox) * lds_ + c8 * 8;
+    const h16x8 a = *reinterpret_cast<const h16x8*>(s0), bq = *reinterpret_cast<const h16x8*>(s0 + lds_);
+    const h16x8 c = *reinterpret_cast<const h16x8*>(s0 + (size_t)W * lds_), d = *reinterpret_cast<const h16x8*>(s0 + (size_t)W * lds_ + lds_);
+    h16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (h16)fmaxf(fmaxf((float)a[e], (float)bq[e]), fmaxf((float)c[e], (float)d[e]));
+    *reinterpret_cast<h16x8*>(dst + (((size_t)b * Ho + oy) * Wo + ox) * ldd + c8 * 8) = o;
+}
+// bilinear x2 upsampling with align_corners=True, NHWC fp16 (nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+// unet_parts.py:48): source coordinate = dst * (in - 1) / (out - 1)
+__global__ void upsample2x_bilinear_ac_kernel(const h16* __restrict__ src, int lds_, int n, int H, int W, int C, h16* __restrict__ dst, int ldd) {
+    const int Ho = 2 * H, Wo = 2 * W, oc = C / 8;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * Ho * Wo * oc) return;
+    const int c8 = (int)(idx % oc);
+    size_t p = idx / oc;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho); const int b = (int)(p / Ho);
+    const float sy = Ho > 1 ? (float)oy * (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)ox * (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float fy = sy - (float)y0, fx = sx - (float)x0;
+    const h16* base = src + (size_t)b * H * W * lds_ + c8 * 8;
+    const h16x8 v00 = *reinterpret_cast<const h16x8*>(base + ((size_t)y0 * W + x0) * lds_), v01 = *reinterpret_cast<const h16x8*>(base + ((size_t)y0 * W + x1) * lds_);
+    const h16x8 v10 = *reinterpret_cast<const h16x8*>(base + ((size_t)y1 * W + x0) * lds_), v11 = *reinterpret_cast<const h16x8*>(base + ((size_t)y1 * W + x1) * lds_);
+    h16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float top = (float)v00[e] + ((float)v01[e] - (float)v00[e]) * fx;
+        const float bot = (float)v10[e] + ((float)v11[e] - (float)v10[e]) * fx;
+        o[e] = (h16)(top + (bot - top) * fy);
+    }
+    *reinterpret_cast<h16x8*>(dst + (((size_t)b * Ho + oy) * Wo + ox) * ldd + c8 * 8) = o;
+}
+int ladi_launch_maxpool2(const h16* src, int lds_, int n, int H, int W, int C, h16* dst, int ldd, hipStream_t st) {
+    if ((C & 7) || (lds_ & 7) || (ldd & 7) || (H & 1) || (W & 1)) return -1;
+    const size_t total = (size_t)n * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, lds_, n, H, W, C, dst, ldd);
+    return ok();
+}
+int ladi_launch_upsample2x_bilinear_ac(const h16* src, int lds_, int n, int H, int W, int C, h16* dst, int ldd, hipStream_t st) {
+    if ((C & 7) || (lds_ & 7) || (ldd & 7)) return -1;
+    const size_t total = (size_t)n * (2 * H) * (2 * W) * (C / 8);
+    hipLaunchKernelGGL(upsample2x_bilinear_ac_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, lds_, n, H, W, C, dst, ldd);
+    return ok();
 }
 
 // ViT patch extraction for the bias-free patch-embedding conv (kernel = stride = ps): rows [B][1 + G*G][KP], row 0 (class-token slot)

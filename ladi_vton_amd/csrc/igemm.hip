@@ -308,6 +308,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void igemm_kernel(const IGemmArgs 
                             if (rowadd && (co + e) < Qout) x += rowadd[co + e];
                             if (a.act == LADI_ACT_SILU) x = silu_f(x);
                             else if (a.act == LADI_ACT_GELU) x = gelu_f(x);
+                            else if (a.act == LADI_ACT_RELU) x = fmaxf(x, 0.f);
                         }
                         o[e] = (h16)(x * a.out_scale);
                     }
@@ -415,6 +416,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             for (int z = 0; z < S; ++z) x += part[(size_t)z * slice + (size_t)p * a.Q + c];
             if (a.act == LADI_ACT_SILU) x = silu_f(x);
             else if (a.act == LADI_ACT_GELU) x = gelu_f(x);
+            else if (a.act == LADI_ACT_RELU) x = fmaxf(x, 0.f);
             x = (float)(h16)(x * a.out_scale);   // same rounding point as the fused epilogue (fp16 before the residual add)
             if (a.res0) x += (float)a.res0[(size_t)p * a.ldr0 + c];
             if (a.res1) x += (float)a.res1[(size_t)p * a.ldr1 + c];

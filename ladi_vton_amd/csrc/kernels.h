@@ -102,6 +102,9 @@ int ladi_launch_fill_f32(float* p, size_t n, float v, hipStream_t st);
 // wemb fp16 [B][nv][H] or null; out [B][T][H] = (token | pseudo-word) embedding + position embedding
 int ladi_launch_text_embed(const int* ids, const int* first, int nv, const h16* tok, const h16* pos, const h16* wemb, int B, int T,
                            int H, h16* out, hipStream_t st);
+// refinement UNet helpers (NHWC fp16, C % 8 == 0): 2x2 max pooling; bilinear x2 upsampling with align_corners=True
+int ladi_launch_maxpool2(const h16* src, int lds_, int n, int H, int W, int C, h16* dst, int ldd, hipStream_t st);
+int ladi_launch_upsample2x_bilinear_ac(const h16* src, int lds_, int n, int H, int W, int C, h16* dst, int ldd, hipStream_t st);
 // ViT patch rows for the patch-embedding GEMM: out [B][1 + (S/ps)^2][KP] fp16, row 0 and the padding columns zero
 int ladi_launch_patchify(const void* px, int in_f32, int B, int S, int ps, int KP, h16* out, hipStream_t st);
 int ladi_launch_gather_rows(const h16* src, const int* rows, int n, int H, h16* dst, hipStream_t st);

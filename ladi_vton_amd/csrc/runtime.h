@@ -225,6 +225,19 @@ struct VisionEncoder {
     int forward(const void* pixels, int in_f32, int B, h16* out_hidden, h16* out_pooled, hipStream_t st);
 };
 
+// Refinement UNet of the warping module (first half): src/models/UNet.py UNetVanilla(24, 3, bilinear=True) as
+// instantiated by hubconf.py:57 and called at src/inference.py:264.  BatchNorm (inference mode) is folded into the bias-free convs.
+struct RefineCfg { int in_ch = 24, out_ch = 3, base = 64; float bn_eps = 1e-5f; };
+struct DoubleConvW { DConv c1, c2; };
+struct Refine {
+    RefineCfg cfg; DevPool pool;
+    DoubleConvW inc, down[4], up[4]; DConv outc;
+    Arena arena;
+    void load(const RefineCfg& c, const WeightStore& ws);
+    // x [B, in_ch, H, W] NCHW fp32/fp16 (device) -> out [B, out_ch, H, W] NCHW fp32/fp16; H, W multiples of 16
+    int forward(const void* x, int in_f32, int B, int H, int W, void* out, int out_f32, hipStream_t st);
+};
+
 struct TryOnInputs {
     int batch, height, width, in_f32;
     const void *image, *mask_image, *pose_map, *warped_cloth;

@@ -329,6 +329,34 @@ def test_flash_attention_forced_rescale_two_query_blocks(lib):
     assert U.rel_l2(O[3, 32:64, 64:128].float().cpu(), ref[3, 32:64, 64:128]) < 3e-3
 
 
+# --------------------------------------------------------------------------------------------------------------- refinement UNet helpers
+def test_maxpool2_and_bilinear_upsample(lib):
+    """nn.MaxPool2d(2) and nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) on NHWC fp16 (unet_parts.py:33-36,48)"""
+    n, C, H, W = 2, 72, 10, 6
+    x = _rand((n, C, H, W), 260)
+    xs = x.permute(0, 2, 3, 1).half().contiguous().to(U.dev())      # dense NHWC, C = 72 (8-channel vectors, not a multiple of 64)
+    ref_p = F.max_pool2d(x.half().float(), 2)
+    out_p = torch.empty((n, H // 2, W // 2, C), dtype=torch.float16, device=U.dev())
+    assert lib.ladi_op_maxpool2(ptr(xs), n, H, W, C, ptr(out_p), stream_ptr()) == 0
+    ref_u = F.interpolate(x.half().float(), scale_factor=2, mode="bilinear", align_corners=True)
+    out_u = torch.empty((n, 2 * H, 2 * W, C), dtype=torch.float16, device=U.dev())
+    assert lib.ladi_op_upsample2x_bilinear(ptr(xs), n, H, W, C, ptr(out_u), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(U.to_nchw(out_p), ref_p)
+    assert U.rel_l2(U.to_nchw(out_u), ref_u) < 1e-3
+
+
+def test_conv3x3_relu_two_source(lib):
+    """ReLU epilogue + two-source concat K loop (the Up block's cat([skip, up]) -> conv -> folded BN -> ReLU)"""
+    N, c0, c1, cout, h, w = 1, 64, 64, 128, 12, 8
+    x0, x1 = _rand((N, c0, h, w), 261), _rand((N, c1, h, w), 262)
+    wt, b = _rand((cout, c0 + c1, 3, 3), 263, 1 / math.sqrt(9 * (c0 + c1))), _rand((cout,), 264, 0.3)
+    ref = F.relu(F.conv2d(torch.cat([x0, x1], 1), wt, b, padding=1))
+    y = U.igemm(U.nhwc16(x0), U.pack_conv_weight_cat(wt, c0, c1), cout, x2=U.nhwc16(x1), bias=b, act="relu")
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+    assert float(U.to_nchw(y).min()) == 0.0
+
+
 # --------------------------------------------------------------------------------------------------------------- misc
 def test_small_linear(lib):
     M, N, K = 19, 100, 320

@@ -7,7 +7,7 @@ import torch
 from ladi_vton_amd import _lib
 from ladi_vton_amd._lib import IGemmDesc, ptr, stream_ptr
 
-ACT = dict(none=0, silu=1, gelu=2, geglu=3)
+ACT = dict(none=0, silu=1, gelu=2, geglu=3, relu=4)
 
 
 def dev():
