@@ -163,6 +163,22 @@ void ladi_refine_destroy(ladi_refine* r);
 int ladi_refine_forward(ladi_refine* r, const void* x_dev, int dtype, int B, int H, int W, void* out_dev, int out_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * TPS geometric-matching network of the warping module — replaces the inference data flow of src/models/ConvNet_TPS.py
+ * ConvNet_TPS.forward (:315-337) as instantiated by hubconf.py:56 (256x192, input_nc 21, n_layer 3) and called at
+ * src/inference.py:253 (`low_grid, theta, ... = tps(low_cloth, agnostic)`).  SURVEY.md §8(f) rank 3 (second half).
+ * The training-only regulariser outputs (rx, ry, cx, cy, rg, cg; :201-224) are not produced.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct { int height, width, input_nc, n_layers, grid_size, ngf; float bn_eps; } ladi_tps_config;
+typedef struct ladi_tps ladi_tps;
+/* weights: the 'tps' state_dict of the released warping checkpoint (hubconf.py:61); gridGen.* buffers are recomputed, not read */
+ladi_tps* ladi_tps_create(const ladi_tps_config* cfg, const ladi_weights* ws);
+void ladi_tps_destroy(ladi_tps* t);
+/* input_a_dev [B,3,H,W], input_b_dev [B,input_nc,H,W] NCHW (dtype 0 fp32 / 1 fp16); grid_dev: fp32 [B,H,W,2] sampling grid in [-1,1]
+ * (x, y) as F.grid_sample expects; coor_dev: fp32 [B, grid_size^2, 2] source control points (theta) or NULL */
+int ladi_tps_forward(ladi_tps* t, const void* input_a_dev, const void* input_b_dev, int dtype, int B, float* grid_dev, float* coor_dev,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Scheduler — replaces diffusers DDIMScheduler / PNDMScheduler (skip_prk_steps) set_timesteps + step
  * (tryon_pipe.py:650-651,740).  kind: 0 = DDIM, 1 = PNDM.
  * ------------------------------------------------------------------------------------------------------------- */

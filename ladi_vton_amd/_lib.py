@@ -52,6 +52,11 @@ class RefineConfig(Structure):
     _fields_ = [("in_channels", c_int), ("out_channels", c_int), ("base_channels", c_int), ("bn_eps", c_float)]
 
 
+class TpsConfig(Structure):
+    _fields_ = [("height", c_int), ("width", c_int), ("input_nc", c_int), ("n_layers", c_int), ("grid_size", c_int), ("ngf", c_int),
+                ("bn_eps", c_float)]
+
+
 class TryOnInputs(Structure):
     _fields_ = [("batch", c_int), ("height", c_int), ("width", c_int), ("in_dtype", c_int),
                 ("image_dev", c_void_p), ("mask_image_dev", c_void_p), ("pose_map_dev", c_void_p), ("warped_cloth_dev", c_void_p),
@@ -103,6 +108,9 @@ SIGNATURES = {
     "ladi_vision_encoder_create": (_P, [POINTER(VisionConfig), _P]),
     "ladi_vision_encoder_destroy": (None, [_P]),
     "ladi_vision_encoder_forward": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
+    "ladi_tps_create": (_P, [POINTER(TpsConfig), _P]),
+    "ladi_tps_destroy": (None, [_P]),
+    "ladi_tps_forward": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P]),
     "ladi_refine_create": (_P, [POINTER(RefineConfig), _P]),
     "ladi_refine_destroy": (None, [_P]),
     "ladi_refine_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),

@@ -17,6 +17,7 @@ struct ladi_adapter { Adapter a; };
 struct ladi_text_encoder { TextEncoder t; };
 struct ladi_vision_encoder { VisionEncoder v; };
 struct ladi_refine { Refine r; };
+struct ladi_tps { Tps t; };
 struct ladi_tryon { TryOn t; };
 
 static_assert(sizeof(ladi_igemm_desc) == sizeof(IGemmArgs), "public igemm descriptor must mirror IGemmArgs");
@@ -382,6 +383,31 @@ int ladi_refine_forward(ladi_refine* r, const void* x, int dtype, int B, int H, 
         if (!r || !x || !out) throw std::runtime_error("null argument");
         if ((dtype != 0 && dtype != 1) || (out_dtype != 0 && out_dtype != 1)) throw std::runtime_error("dtype must be fp32 (0) or fp16 (1)");
         return r->r.forward(x, dtype == 0, B, H, W, out, out_dtype == 0, S(stream));
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ TPS matching network
+ladi_tps* ladi_tps_create(const ladi_tps_config* cfg, const ladi_weights* ws) {
+    ladi_tps* h = nullptr;
+    int rc = guarded("ladi_tps_create", [&]() {
+        if (!cfg || !ws) throw std::runtime_error("null argument");
+        require_gpu();
+        TpsCfg c; c.height = cfg->height; c.width = cfg->width; c.input_nc = cfg->input_nc; c.n_layers = cfg->n_layers; c.grid = cfg->grid_size;
+        c.ngf = cfg->ngf; c.bn_eps = cfg->bn_eps;
+        if (c.n_layers != 3 || c.ngf != 64) throw std::runtime_error("TPS: only the released topology (n_layer = 3, ngf = 64) is supported");
+        h = new ladi_tps();
+        h->t.load(c, ws->ws);
+        return 0;
+    });
+    if (rc) { delete h; return nullptr; }
+    return h;
+}
+void ladi_tps_destroy(ladi_tps* t) { delete t; }
+int ladi_tps_forward(ladi_tps* t, const void* a, const void* b, int dtype, int B, float* grid, float* coor, void* stream) {
+    return guarded("ladi_tps_forward", [&]() {
+        if (!t || !a || !b || !grid) throw std::runtime_error("null argument");
+        if (dtype != 0 && dtype != 1) throw std::runtime_error("dtype must be fp32 (0) or fp16 (1)");
+        return t->t.forward(a, b, dtype == 0, B, grid, coor, S(stream));
     });
 }
 

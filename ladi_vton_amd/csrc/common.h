@@ -21,7 +21,8 @@ enum {
     LADI_ACT_SILU = 1,
     LADI_ACT_GELU = 2,   // exact erf GELU
     LADI_ACT_GEGLU = 3,  // igemm only: rows interleaved in blocks of 32 (u | g), out = u * gelu(g)
-    LADI_ACT_RELU = 4    // refinement UNet of the warping module (conv -> folded BatchNorm -> ReLU)
+    LADI_ACT_RELU = 4,   // warping module (conv -> folded BatchNorm -> ReLU)
+    LADI_ACT_TANH = 5    // small_linear only: control-point regression of the TPS network
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

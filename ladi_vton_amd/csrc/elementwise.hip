@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const XT* __restrict_
             if (act == LADI_ACT_SILU) s = silu_f(s);
             else if (act == LADI_ACT_GELU) s = gelu_f(s);
             else if (act == LADI_ACT_RELU) s = fmaxf(s, 0.f);
+            else if (act == LADI_ACT_TANH) s = tanhf(s);
             if (res) s += (float)res[(size_t)m * ldr + nn];
             if (out_f32) reinterpret_cast<float*>(out)[(size_t)m * ldo + nn] = s;
             else reinterpret_cast<h16*>(out)[(size_t)m * ldo + nn] = (h16)s;
@@ -446,6 +447,89 @@ __global__ void text_embed_kernel(const int* __restrict__ ids, const int* __rest
 __global__ void gather_rows_kernel(const h16* __restrict__ src, const int* __restrict__ rows, int H, h16* __restrict__ dst) {
     const h16* s = src + (size_t)rows[blockIdx.x] * H;
     for (int c = threadIdx.x; c < H; c += blockDim.x) dst[(size_t)blockIdx.x * H + c] = s[c];
+}
+
+// y = x * scale[c] + shift[c] per channel (inference-mode BatchNorm that FOLLOWS a ReLU: ConvNet_TPS.py:31-43), NHWC fp16, in place ok
+__global__ void channel_affine_kernel(const h16* __restrict__ x, int ldx, size_t n_pix, int C, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, h16* __restrict__ y, int ldy) {
+    const int oc = C / 8;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pix * oc) return;
+    const int c8 = (int)(idx % oc);
+    const size_t p = idx / oc;
+    const h16x8 v = *reinterpret_cast<const h16x8*>(x + p * ldx + c8 * 8);
+    h16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (h16)((float)v[e] * scale[c8 * 8 + e] + shift[c8 * 8 + e]);
+    *reinterpret_cast<h16x8*>(y + p * ldy + c8 * 8) = o;
+}
+// FeatureL2Norm (ConvNet_TPS.py:59-66): every pixel's channel vector divided by sqrt(sum of squares + 1e-6); one wave per pixel
+__global__ void l2norm_rows_kernel(const h16* __restrict__ x, int ldx, int rows, int C, h16* __restrict__ y, int ldy) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const h16* xr = x + (size_t)row * ldx;
+    float ss = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        const h16x8 v = *reinterpret_cast<const h16x8*>(xr + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.f / sqrtf(ss + 1e-6f);
+    for (int c = lane * 8; c < C; c += 512) {
+        const h16x8 v = *reinterpret_cast<const h16x8*>(xr + c);
+        h16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (h16)((float)v[e] * inv);
+        *reinterpret_cast<h16x8*>(y + (size_t)row * ldy + c) = o;
+    }
+}
+// TPSGridGen.forward (ConvNet_TPS.py:172-185): grid[b][y][x] = [phi(p, c_0..c_{N-1}), 1, X, Y] . (inverse_kernel . [coor_b; 0; 0; 0]),
+// phi(r^2) = 0.5 r^2 log r^2 (0 at r = 0), p = (X, Y) = (2x/(W-1) - 1, 2y/(H-1) - 1).  N <= 32 control points.
+__global__ void tps_grid_kernel(const float* __restrict__ coor, const float* __restrict__ inv, const float* __restrict__ ctrl, int N,
+                                int H, int W, float* __restrict__ grid) {
+    __shared__ float map[35][2];
+    __shared__ float sc[32][2];
+    const int b = blockIdx.y, M = N + 3;
+    for (int i = threadIdx.x; i < M * 2; i += blockDim.x) {
+        const int r = i >> 1, d = i & 1;
+        float s = 0.f;
+        for (int k = 0; k < N; ++k) s += inv[r * M + k] * coor[((size_t)b * N + k) * 2 + d];
+        map[r][d] = s;
+    }
+    for (int i = threadIdx.x; i < N * 2; i += blockDim.x) sc[i >> 1][i & 1] = ctrl[i];
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    const float X = (float)x * 2.f / (float)(W - 1) - 1.f, Y = (float)y * 2.f / (float)(H - 1) - 1.f;
+    float gx = map[N][0] + X * map[N + 1][0] + Y * map[N + 2][0];
+    float gy = map[N][1] + X * map[N + 1][1] + Y * map[N + 2][1];
+    for (int k = 0; k < N; ++k) {
+        const float dx = X - sc[k][0], dy = Y - sc[k][1];
+        const float r2 = dx * dx + dy * dy;
+        const float phi = r2 > 0.f ? 0.5f * r2 * logf(r2) : 0.f;
+        gx += phi * map[k][0];
+        gy += phi * map[k][1];
+    }
+    float* o = grid + ((size_t)b * H * W + p) * 2;
+    o[0] = gx; o[1] = gy;
+}
+int ladi_launch_channel_affine(const h16* x, int ldx, size_t n_pix, int C, const float* scale, const float* shift, h16* y, int ldy, hipStream_t st) {
+    if ((C & 7) || (ldx & 7) || (ldy & 7)) return -1;
+    const size_t total = n_pix * (size_t)(C / 8);
+    hipLaunchKernelGGL(channel_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, ldx, n_pix, C, scale, shift, y, ldy);
+    return ok();
+}
+int ladi_launch_l2norm_rows(const h16* x, int ldx, int rows, int C, h16* y, int ldy, hipStream_t st) {
+    if ((C & 7) || (ldx & 7) || (ldy & 7)) return -1;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, rows, C, y, ldy);
+    return ok();
+}
+int ladi_launch_tps_grid(const float* coor, const float* inv, const float* ctrl, int N, int B, int H, int W, float* grid, hipStream_t st) {
+    if (N < 1 || N > 32 || H < 2 || W < 2) return -1;
+    hipLaunchKernelGGL(tps_grid_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)B), dim3(256), 0, st, coor, inv, ctrl, N, H, W, grid);
+    return ok();
 }
 
 // 2x2 max pooling, NHWC fp16 (nn.MaxPool2d(2) of the refinement UNet, unet_parts.py:33-36); 8 channels per thread

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void igemm_kernel(const IGemmArgs 
 
     auto issue = [&](int stage) {
         int dy = 0, dx = 0;
-        if (a.ksize == 3) { dy = tap / 3; dx = tap - dy * 3; }
+        if (a.ksize > 1) { dy = tap / a.ksize; dx = tap - dy * a.ksize; }
         const bool s0 = cb < a.C0;
         const __amdgpu_buffer_rsrc_t rs = s0 ? rs0 : rs1;
         const int ld = s0 ? a.ld0 : a.ld1;
@@ -567,7 +567,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     IGemmArgs a = a_in;
     const int cfg_in = cfg;
     if (stats_row_px) *stats_row_px = 0;
-    if (a.ksize != 1 && a.ksize != 3) return -1;
+    if (a.ksize != 1 && a.ksize != 3 && a.ksize != 4) return -1;   // 4: the stride-2 convs of the TPS matching network
     if ((a.C0 % 32) || (a.C1 % 32)) return -2;
     if (a.K != a.ksize * a.ksize * (a.C0 + a.C1)) return -3;
     if ((a.ld0 % 8) || (a.C1 && (a.ld1 % 8)) || (a.K % 8) || (a.ldw % 8)) return -4;

@@ -102,6 +102,11 @@ int ladi_launch_fill_f32(float* p, size_t n, float v, hipStream_t st);
 // wemb fp16 [B][nv][H] or null; out [B][T][H] = (token | pseudo-word) embedding + position embedding
 int ladi_launch_text_embed(const int* ids, const int* first, int nv, const h16* tok, const h16* pos, const h16* wemb, int B, int T,
                            int H, h16* out, hipStream_t st);
+// TPS matching network helpers: per-channel affine (BatchNorm after ReLU), per-pixel L2 normalisation over channels, TPS grid
+int ladi_launch_channel_affine(const h16* x, int ldx, size_t n_pix, int C, const float* scale, const float* shift, h16* y, int ldy, hipStream_t st);
+int ladi_launch_l2norm_rows(const h16* x, int ldx, int rows, int C, h16* y, int ldy, hipStream_t st);
+// coor [B][N][2], inv [(N+3)^2], ctrl [N][2] (all fp32, device) -> grid [B][H][W][2] fp32
+int ladi_launch_tps_grid(const float* coor, const float* inv, const float* ctrl, int N, int B, int H, int W, float* grid, hipStream_t st);
 // refinement UNet helpers (NHWC fp16, C % 8 == 0): 2x2 max pooling; bilinear x2 upsampling with align_corners=True
 int ladi_launch_maxpool2(const h16* src, int lds_, int n, int H, int W, int C, h16* dst, int ldd, hipStream_t st);
 int ladi_launch_upsample2x_bilinear_ac(const h16* src, int lds_, int n, int H, int W, int C, h16* dst, int ldd, hipStream_t st);

@@ -238,6 +238,23 @@ struct Refine {
     int forward(const void* x, int in_f32, int B, int H, int W, void* out, int out_f32, hipStream_t st);
 };
 
+// TPS geometric-matching network of the warping module (second half): src/models/ConvNet_TPS.py ConvNet_TPS as
+// instantiated by hubconf.py:56 (256x192, input_nc = 21, n_layer = 3) and called at src/inference.py:253
+struct TpsCfg { int height = 256, width = 192, input_nc = 21, n_layers = 3, grid = 5, ngf = 64; float bn_eps = 1e-5f; };
+struct TpsExtract { std::vector<DConv> conv; std::vector<float*> bn_scale, bn_shift; };   // conv i -> ReLU -> (BatchNorm i, except after the last)
+struct Tps {
+    TpsCfg cfg; DevPool pool;
+    TpsExtract ea, eb;
+    DConv reg[4]; DConv lin;          // regression convs (BatchNorm folded) and the control-point linear (columns permuted to NHWC order)
+    float* d_inv = nullptr; float* d_ctrl = nullptr;   // TPSGridGen inverse kernel [(N+3)^2], target control points [N][2]
+    int* d_perm = nullptr; int perm_cap = 0;           // correlation row order of feature A (column-major positions)
+    Arena arena;
+    void load(const TpsCfg& c, const WeightStore& ws);
+    // a [B,3,H,W], b [B,input_nc,H,W] NCHW fp32/fp16 (device) -> grid [B,H,W,2] fp32, coor [B,grid*grid,2] fp32 (or null)
+    int forward(const void* a, const void* b, int in_f32, int B, float* grid, float* coor, hipStream_t st);
+    ~Tps();
+};
+
 struct TryOnInputs {
     int batch, height, width, in_f32;
     const void *image, *mask_image, *pose_map, *warped_cloth;

@@ -1,18 +1,20 @@
-"""Warping-module pieces over libladi_native.  Built so far: the refinement UNet — drop-in for the `refinement`
-nn.Module of hubconf.py:57 (src/models/UNet.py UNetVanilla(24, 3, bilinear=True)) called at src/inference.py:264:
+"""Warping module over libladi_native: drop-ins for the two nn.Modules hubconf.py:56-58 returns.
 
-    refinement = NativeRefinementUNet(configs.REFINE_FULL, refinement.state_dict())     # once, after hubconf's load_state_dict
-    warped_cloth = refinement(torch.cat([im_mask, pose_map, warped_cloth], 1).to(torch.float32)).clamp(-1, 1)
+    tps, refinement = NativeTPS(configs.TPS_FULL, tps.state_dict()), NativeRefinementUNet(configs.REFINE_FULL, refinement.state_dict())
+    low_grid, theta, rx, ry, cx, cy, rg, cg = tps(low_cloth.to(torch.float32), agnostic.to(torch.float32))          # inference.py:253
+    warped_cloth = refinement(torch.cat([im_mask, pose_map, warped_cloth], 1).to(torch.float32)).clamp(-1, 1)       # inference.py:263-265
 
-Returns a tensor of the input's dtype (fp32 in the reference's call) and shape [B, 3, H, W]; H and W must be multiples of 16 (512x384 in
-the reference).  The TPS matching network (ConvNet_TPS) is not native yet; its oracle is pinned (oracle/warp.py).  No CPU fallback.
+`NativeTPS` returns the sampling grid [B, 256, 192, 2] (fp32, what F.grid_sample consumes) and the source control points `theta`
+[B, 25, 2]; the six training-only regulariser values of the reference's 8-tuple are returned as None (inference.py never reads them).
+`NativeRefinementUNet` returns a tensor of the input's dtype, [B, 3, H, W], H and W multiples of 16.  The resizes and the grid_sample call
+between the two stay on the caller's side (torchvision / torch.nn.functional, inference.py:242-260).  No CPU fallback.
 """
 import ctypes
 
 import torch
 
 from . import _lib
-from ._lib import NativeError, RefineConfig, check, dtype_code, ptr, stream_ptr
+from ._lib import NativeError, RefineConfig, TpsConfig, check, dtype_code, ptr, stream_ptr
 from .modules import _Weights
 
 
@@ -51,3 +53,40 @@ class NativeRefinementUNet:
         out = torch.empty((B, self.cfg["out_channels"], H, W), dtype=xin.dtype, device=self.device)
         check(self.lib.ladi_refine_forward(self.h, ptr(xin), dtype_code(xin), B, H, W, ptr(out), dtype_code(out), stream_ptr()), "ladi_refine_forward")
         return out
+
+
+class NativeTPS:
+    def __init__(self, cfg, state_dict):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        c = TpsConfig()
+        c.height, c.width, c.input_nc, c.n_layers, c.grid_size, c.ngf = cfg["height"], cfg["width"], cfg["input_nc"], cfg["n_layers"], cfg["grid"], cfg["ngf"]
+        c.bn_eps = cfg.get("bn_eps", 1e-5)
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked") and not k.startswith("gridGen.")}
+        with _Weights(sd) as w:
+            self.h = self.lib.ladi_tps_create(ctypes.byref(c), w.h)
+        if not self.h:
+            raise NativeError("ladi_tps_create failed: " + _lib.last_error())
+        self.cfg = dict(cfg)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ladi_tps_destroy(self.h)
+            self.h = None
+
+    def eval(self):
+        return self
+
+    def __call__(self, input_a, input_b):
+        H, W = self.cfg["height"], self.cfg["width"]
+        if tuple(input_a.shape[1:]) != (3, H, W) or tuple(input_b.shape[1:]) != (self.cfg["input_nc"], H, W) or input_a.shape[0] != input_b.shape[0]:
+            raise ValueError("expected inputA [B, 3, %d, %d] and inputB [B, %d, %d, %d]" % (H, W, self.cfg["input_nc"], H, W))
+        dt = torch.float16 if input_a.dtype == torch.float16 and input_b.dtype == torch.float16 else torch.float32
+        a = input_a.to(device=self.device, dtype=dt).contiguous()
+        b = input_b.to(device=self.device, dtype=dt).contiguous()
+        B, N = a.shape[0], self.cfg["grid"] ** 2
+        grid = torch.empty((B, H, W, 2), dtype=torch.float32, device=self.device)
+        coor = torch.empty((B, N, 2), dtype=torch.float32, device=self.device)
+        check(self.lib.ladi_tps_forward(self.h, ptr(a), ptr(b), dtype_code(a), B, ptr(grid), ptr(coor), stream_ptr()), "ladi_tps_forward")
+        return grid, coor, None, None, None, None, None, None

@@ -346,6 +346,16 @@ def test_maxpool2_and_bilinear_upsample(lib):
     assert U.rel_l2(U.to_nchw(out_u), ref_u) < 1e-3
 
 
+def test_conv4x4_stride2(lib):
+    """4x4 stride-2 pad-1 convolution on the igemm's generic tap loop (FeatureExtraction / FeatureRegression, ConvNet_TPS.py:31,95)"""
+    N, cin, cout, h, w = 2, 64, 128, 16, 12
+    x, wt, b = _rand((N, cin, h, w), 270), _rand((cout, cin, 4, 4), 271, 1 / math.sqrt(16 * cin)), _rand((cout,), 272, 0.1)
+    ref = F.relu(F.conv2d(x, wt, b, stride=2, padding=1))
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cout, ksize=4, stride=2, pad=1, bias=b, act="relu")
+    assert y.shape[1:3] == (h // 2, w // 2)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+
+
 def test_conv3x3_relu_two_source(lib):
     """ReLU epilogue + two-source concat K loop (the Up block's cat([skip, up]) -> conv -> folded BN -> ReLU)"""
     N, c0, c1, cout, h, w = 1, 64, 64, 128, 12, 8
