@@ -133,10 +133,10 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void igemm_kernel(const IGemmArgs 
         nk = max(0, min(sps, nk - start));
         cb = (start / ntap) * BK; tap = start - (start / ntap) * ntap;
     }
+    int tdy = tap / a.ksize, tdx = tap - (tap / a.ksize) * a.ksize;   // window offset of `tap`, advanced incrementally (no per-step division)
 
     auto issue = [&](int stage) {
-        int dy = 0, dx = 0;
-        if (a.ksize > 1) { dy = tap / a.ksize; dx = tap - dy * a.ksize; }
+        const int dy = tdy, dx = tdx;
         const bool s0 = cb < a.C0;
         const __amdgpu_buffer_rsrc_t rs = s0 ? rs0 : rs1;
         const int ld = s0 ? a.ld0 : a.ld1;
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void igemm_kernel(const IGemmArgs 
             const unsigned vo = ok ? (unsigned)(((nb[i] + iy * a.Ws + ix) * ld + c) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sbase + (BQ * BK * 2) + i * (RPP * BK * 2)), 16, vo, 0, 0, 0);
         }
-        if (++tap == ntap) { tap = 0; cb += BK; }
+        if (++tdx == a.ksize) { tdx = 0; ++tdy; }
+        if (++tap == ntap) { tap = 0; tdy = 0; tdx = 0; cb += BK; }
     };
 
     const int wq = wave / WP, wp = wave % WP;
