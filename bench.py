@@ -145,13 +145,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the native path has no CPU fallback"
+    torch.cuda.set_device(local_rank)          # bind the rank to its GPU before RCCL is initialised
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs a GPU: the native path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     import ladi_vton_amd as L
     from ladi_vton_amd import _lib, configs as C
