@@ -207,7 +207,10 @@ typedef struct {
     int num_inference_steps;
     float guidance_scale;
     int scheduler;                     /* 0 DDIM, 1 PNDM */
-    float cloth_cond_rate;
+    int cloth_zero_from_eval;          /* first evaluation index i that sees zero cloth latents: the smallest i with
+                                        * i >= num_inference_steps - (1 - cloth_cond_rate) * num_inference_steps, evaluated by the CALLER in
+                                        * float64 exactly like tryon_pipe.py:654,718 (a float32 rate crossing the ABI shifts the cut-off by
+                                        * one step for rates such as 0.2 / 0.4 / 0.6 / 0.8); >= the evaluation count: never */
     int no_pose;
     int use_graph;                     /* capture the denoising step into a hipGraph and replay it */
     const float* alphas_cumprod_host;  /* optional [1000] override */
@@ -218,6 +221,10 @@ ladi_tryon* ladi_tryon_create(ladi_unet* unet, ladi_vae* vae, ladi_emasc* emasc)
 void ladi_tryon_destroy(ladi_tryon* t);
 /* images_dev: fp32 [B,H,W,3] in [0,1] (decode_latents layout, tryon_pipe.py:356-358); latents_dev: optional fp32 [B,4,h,w] */
 int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images_dev, float* latents_dev, void* stream);
+/* per-evaluation trace for parity tests (tryon_pipe.py:732-740 intermediate values): subsequent runs write the guided noise prediction
+ * and the updated latents of evaluation i to *_trace_dev[i] (fp32 [B, h*w, 4] each) for i < cap_evals; NULL pointers switch it off.
+ * Buffers are caller-owned and must outlive the runs. */
+int ladi_tryon_set_trace(ladi_tryon* t, float* eps_trace_dev, float* latents_trace_dev, int cap_evals);
 /* stage times (ms) of the last run: [0] preprocess + VAE encodes + EMASC, [1] denoising loop, [2] decode. Sync first. */
 int ladi_tryon_stage_ms(ladi_tryon* t, float* out3);
 /* run ONLY `iters` UNet forwards (n samples of h x w latents, context already set) bracketed by HIP events on `stream`
@@ -270,6 +277,23 @@ int ladi_op_nhwc_to_nchw(const void* src, int ld, int n, int C, int H, int W, vo
  * runs evaluations [0, evals) feeding eps_seq[i] ([2B or B][hw][4] fp16 NHWC per evaluation); latents fp32 [B][hw][4] in/out */
 int ladi_op_sched_run(int kind, int steps, const float* alphas_cumprod_host, const void* eps_seq_dev, int evals, int B, int hw,
                       int cfg, float guidance, float* latents_dev, void* stream);
+/* pipeline pre-processing kernels, one entry point per kernel so each can be checked on its own:
+ * prepare_mask_and_masked_image (diffusers tensor branch; tryon_pipe.py:630): mask binarised at 0.5 -> mask_bin_dev fp16 [B,H,W];
+ *   masked_image_dev NHWC fp16 [B,H,W,ld] (3 valid channels, the rest zero) = image * (mask < 0.5) */
+int ladi_op_prepare_mask(const void* image_dev, const void* mask_dev, int dtype, int B, int H, int W, void* masked_image_dev, int ld,
+                         void* mask_bin_dev, void* stream);
+/* F.interpolate(mask, size=(H/s, W/s)) (nearest; prepare_mask_latents tryon_pipe.py:424-427, mask_features data_utils.py:11) on fp16 [B,H,W] */
+int ladi_op_mask_down(const void* mask_dev, int B, int H, int W, int s, void* out_dev, void* stream);
+/* F.interpolate(pose_map, size=(H/8, W/8), mode="bilinear") (tryon_pipe.py:632-634): NCHW in (dtype) -> NHWC fp16 [B, H/8 * W/8, C] */
+int ladi_op_pose_down8(const void* pose_dev, int dtype, int B, int C, int H, int W, void* out_dev, void* stream);
+/* scaling_factor * DiagonalGaussianDistribution(moments).sample() (vae.py:329-348; tryon_pipe.py:640,647) with the generator draw passed in:
+ * moments NHWC fp16 [B, hw, ldm] (8 channels: mean | logvar), noise fp32 NCHW [B,4,h,w] -> latents fp32 [B, hw, 4] */
+int ladi_op_posterior_sample(const void* moments_dev, int ldm, const float* noise_dev, int B, int hw, float scaling, float* lat_dev,
+                             void* stream);
+/* 31-channel UNet input assembly (tryon_pipe.py:702-729): [latents(4) | mask(1) | masked-image latents(4) | pose(P) | cloth latents(4)],
+ * CFG batch order [uncond(B); cond(B)] with zero pose / cloth in the uncond half; unet_in NHWC fp16 [(cfg ? 2B : B), hw, ld] */
+int ladi_op_assemble_input(void* unet_in_dev, int ld, int B, int hw, int cfg, const float* latents_dev, const void* mask_lat_dev,
+                           const float* masked_lat_dev, const void* pose_dev, int pose_channels, const float* cloth_lat_dev, void* stream);
 
 #ifdef __cplusplus
 }

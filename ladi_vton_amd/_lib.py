@@ -63,7 +63,7 @@ class TryOnInputs(Structure):
                 ("pose_channels", c_int),
                 ("prompt_embeds_dev", c_void_p), ("negative_prompt_embeds_dev", c_void_p), ("L", c_int),
                 ("noise_cloth_dev", c_void_p), ("noise_latents_dev", c_void_p), ("noise_masked_dev", c_void_p),
-                ("num_inference_steps", c_int), ("guidance_scale", c_float), ("scheduler", c_int), ("cloth_cond_rate", c_float),
+                ("num_inference_steps", c_int), ("guidance_scale", c_float), ("scheduler", c_int), ("cloth_zero_from_eval", c_int),
                 ("no_pose", c_int), ("use_graph", c_int), ("alphas_cumprod_host", c_void_p)]
 
 
@@ -123,6 +123,7 @@ SIGNATURES = {
     "ladi_tryon_destroy": (None, [_P]),
     "ladi_tryon_run": (c_int, [_P, POINTER(TryOnInputs), _P, _P, _P]),
     "ladi_tryon_stage_ms": (c_int, [_P, POINTER(c_float)]),
+    "ladi_tryon_set_trace": (c_int, [_P, _P, _P, c_int]),
     "ladi_igemm_set_autotune": (None, [c_int]),
     "ladi_profile_igemm_enable": (None, [c_int]),
     "ladi_profile_igemm_collect": (c_int, [POINTER(ctypes.c_double), c_int]),
@@ -142,6 +143,11 @@ SIGNATURES = {
     "ladi_op_nchw_to_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "ladi_op_nhwc_to_nchw": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "ladi_op_sched_run": (c_int, [c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    "ladi_op_prepare_mask": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "ladi_op_mask_down": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "ladi_op_pose_down8": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "ladi_op_posterior_sample": (c_int, [_P, c_int, _P, c_int, c_int, c_float, _P, _P]),
+    "ladi_op_assemble_input": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P]),
 }
 
 _lib = None
@@ -152,11 +158,13 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        if not build_if_missing:
-            raise NativeError("libladi_native.so is not built (python -m ladi_vton_amd.build)")
+    if build_if_missing:
+        # build() is a no-op when the source digest stamp matches the .so; a stale library (older kernels / ABI structs than the ctypes
+        # mirrors below) must never be loaded silently
         from . import build as _build
         _build.build()
+    elif not os.path.exists(LIB_PATH):
+        raise NativeError("libladi_native.so is not built (python -m ladi_vton_amd.build)")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly

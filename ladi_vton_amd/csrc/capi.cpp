@@ -417,7 +417,7 @@ int ladi_sched_timesteps(int kind, int steps, int* out, int cap) {
         if (steps < 2 || steps > 1000) throw std::runtime_error("num_inference_steps out of range");
         std::vector<float> ac; default_alphas_cumprod(ac);
         std::vector<int> ts; std::vector<StepTable> tb;
-        build_step_table(kind, steps, ac.data(), 1.0f, ts, tb);
+        build_step_table(kind, steps, ac.data(), 1 << 30, ts, tb);
         if ((int)ts.size() > cap) throw std::runtime_error("timesteps buffer too small");
         for (size_t i = 0; i < ts.size(); ++i) out[i] = ts[i];
         return (int)ts.size();
@@ -450,7 +450,7 @@ int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images, fl
         ti.L = in->L;
         ti.noise_cloth = in->noise_cloth_dev; ti.noise_latents = in->noise_latents_dev; ti.noise_masked = in->noise_masked_dev;
         ti.steps = in->num_inference_steps; ti.guidance = in->guidance_scale; ti.scheduler = in->scheduler;
-        ti.cloth_cond_rate = in->cloth_cond_rate; ti.no_pose = in->no_pose; ti.use_graph = in->use_graph;
+        ti.cloth_zero_from = in->cloth_zero_from_eval; ti.no_pose = in->no_pose; ti.use_graph = in->use_graph;
         ti.alphas_cumprod = in->alphas_cumprod_host;
         if (ti.steps < 2 || ti.steps > 1000) throw std::runtime_error("num_inference_steps out of range");
         if (!ti.image || !ti.mask_image || !ti.pose_map || !ti.prompt_embeds || !ti.noise_latents || !ti.noise_masked) throw std::runtime_error("missing input");
@@ -459,6 +459,11 @@ int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images, fl
     });
 }
 int ladi_tryon_stage_ms(ladi_tryon* t, float* out3) { return t ? t->t.stage_ms(out3) : -1; }
+int ladi_tryon_set_trace(ladi_tryon* t, float* eps_trace, float* latents_trace, int cap_evals) {
+    if (!t || cap_evals < 0) return -1;
+    t->t.trace_eps = eps_trace; t->t.trace_lat = latents_trace; t->t.trace_cap = (eps_trace || latents_trace) ? cap_evals : 0;
+    return 0;
+}
 
 void ladi_igemm_set_autotune(int on) { ladi_igemm_autotune(on); }
 void ladi_profile_igemm_enable(int on) { ladi_igemm_profile_enable(on); }
@@ -543,6 +548,25 @@ int ladi_op_nchw_to_nhwc(const void* src, int dtype, int n, int C, int H, int W,
 int ladi_op_nhwc_to_nchw(const void* src, int ld, int n, int C, int H, int W, void* dst, int dtype, void* stream) {
     return ladi_launch_nhwc_to_nchw((const h16*)src, ld, n, C, H, W, dst, dtype == LADI_F32, S(stream));
 }
+int ladi_op_prepare_mask(const void* image, const void* mask, int dtype, int B, int H, int W, void* masked, int ld, void* mask_bin, void* stream) {
+    return ladi_launch_prepare_mask(image, dtype == LADI_F32, mask, dtype == LADI_F32, B, H, W, (h16*)masked, ld, (h16*)mask_bin, S(stream));
+}
+int ladi_op_mask_down(const void* mask, int B, int H, int W, int s, void* out, void* stream) {
+    if (s <= 0 || H % s || W % s) return -1;
+    return ladi_launch_mask_down((const h16*)mask, B, H, W, s, (h16*)out, S(stream));
+}
+int ladi_op_pose_down8(const void* pose, int dtype, int B, int C, int H, int W, void* out, void* stream) {
+    if (H % 8 || W % 8) return -1;
+    return ladi_launch_pose_down8(pose, dtype == LADI_F32, B, C, H, W, (h16*)out, S(stream));
+}
+int ladi_op_posterior_sample(const void* moments, int ldm, const float* noise, int B, int hw, float scaling, float* lat, void* stream) {
+    return ladi_launch_posterior_sample((const h16*)moments, ldm, noise, B, hw, scaling, lat, S(stream));
+}
+int ladi_op_assemble_input(void* unet_in, int ld, int B, int hw, int cfg, const float* latents, const void* mask_lat, const float* masked_lat,
+                           const void* pose, int pose_ch, const float* cloth_lat, void* stream) {
+    return ladi_launch_assemble_static((h16*)unet_in, ld, B, hw, cfg, latents, (const h16*)mask_lat, masked_lat, (const h16*)pose, pose_ch,
+                                       cloth_lat, cloth_lat ? 1 : 0, S(stream));
+}
 int ladi_op_sched_run(int kind, int steps, const float* ac_host, const void* eps_seq, int evals, int B, int hw, int cfg, float guidance,
                       float* latents, void* stream) {
     return guarded("ladi_op_sched_run", [&]() {
@@ -550,7 +574,7 @@ int ladi_op_sched_run(int kind, int steps, const float* ac_host, const void* eps
         std::vector<float> ac;
         if (ac_host) ac.assign(ac_host, ac_host + 1000); else default_alphas_cumprod(ac);
         std::vector<int> ts; std::vector<StepTable> tb;
-        build_step_table(kind, steps, ac.data(), 1.0f, ts, tb);
+        build_step_table(kind, steps, ac.data(), 1 << 30, ts, tb);
         if (evals > (int)tb.size()) throw std::runtime_error("evals exceeds scheduler length");
         char* buf = nullptr;
         const size_t plane = (size_t)B * hw * 4 * sizeof(float);

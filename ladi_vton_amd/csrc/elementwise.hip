@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const StepArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;  // (b, pixel)
     const int total = a.B * a.hw;
     if (idx >= total) return;
-    const StepTable T = a.table[*a.step_idx];
+    const int step = *a.step_idx;
+    const StepTable T = a.table[step];
     const int b = idx / a.hw;
     const size_t row_u = (size_t)idx;                       // uncond (or only) row
     const size_t row_c = (size_t)idx + (size_t)total;       // cond row when cfg
@@ -165,6 +166,10 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const StepArgs a) {
     xn.x = T.c_x * x.x + T.c_e * ec[0]; xn.y = T.c_x * x.y + T.c_e * ec[1];
     xn.z = T.c_x * x.z + T.c_e * ec[2]; xn.w = T.c_x * x.w + T.c_e * ec[3];
     reinterpret_cast<float4*>(a.latents)[idx] = xn;
+    if (step < a.trace_cap) {
+        if (a.trace_eps) reinterpret_cast<float4*>(a.trace_eps)[(size_t)step * total + idx] = make_float4(e[0], e[1], e[2], e[3]);
+        if (a.trace_lat) reinterpret_cast<float4*>(a.trace_lat)[(size_t)step * total + idx] = xn;
+    }
     if (a.unet_in) {
         h16x4 o; o[0] = (h16)xn.x; o[1] = (h16)xn.y; o[2] = (h16)xn.z; o[3] = (h16)xn.w;
         *reinterpret_cast<h16x4*>(a.unet_in + row_u * a.ld_in) = o;

@@ -439,16 +439,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// Fallback split-K workspace for launches that bring none (op-level entry points, one-off GEMMs outside a planned arena).  GROW-ONLY and
+// never freed while the process lives: a captured hipGraph bakes the pointer its launches were recorded with, so a buffer that was ever
+// handed out must stay valid (retired buffers are kept; growth is geometric, so the waste is bounded by the largest request).  The module
+// graphs do not use it: their slabs come from the handle's planned arena (launch_conv_into), whose base address is part of the graph key.
 float* g_ws = nullptr;
 size_t g_ws_bytes = 0;
+std::vector<float*> g_ws_retired;
 bool ensure_ws(size_t bytes, hipStream_t st) {
     if (bytes <= g_ws_bytes) return true;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;  // cannot allocate in a capture
-    if (g_ws) (void)hipFree(g_ws);
-    g_ws = nullptr; g_ws_bytes = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&g_ws), bytes) != hipSuccess) return false;
-    g_ws_bytes = bytes;
+    const size_t want = std::max(bytes, 2 * g_ws_bytes);
+    float* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), want) != hipSuccess) return false;
+    if (g_ws) g_ws_retired.push_back(g_ws);
+    g_ws = p; g_ws_bytes = want;
     return true;
 }
 
@@ -564,7 +570,21 @@ void tune_cache_append(const TuneKey& k, int cfg) {
 
 int ladi_igemm_num_cfgs() { return NCFG; }
 
-int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st, int* stats_row_px) {
+// the split-K admission rule (shared by the tuner and the workspace planner): few output tiles, deep K
+static bool splitk_admissible(const IGemmArgs& a, int c) {
+    const long long tiles = (long long)((a.Q + kCfg[c].bq - 1) / kCfg[c].bq) * ((a.P + kCfg[c].bp - 1) / kCfg[c].bp);
+    return !(tiles * kCfg[c].split > 1024 || tiles > 256 || (a.K / 64) / kCfg[c].split < 8);
+}
+
+size_t ladi_igemm_splitk_ws_bytes(const IGemmArgs& a, int batch) {
+    if (batch != 1 || a.act == LADI_ACT_GEGLU || a.out_f32 || a.bias_per_pixel || a.P <= 0 || a.Q <= 0) return 0;
+    int smax = 0;
+    for (int c = 1; c <= NCFG; ++c)
+        if (kCfg[c].split > 1 && kCfg[c].base != 23 && splitk_admissible(a, c)) smax = std::max(smax, kCfg[c].split);
+    return (size_t)smax * (size_t)a.P * (size_t)a.Q * sizeof(float);
+}
+
+int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st, int* stats_row_px, float* ws, size_t ws_bytes) {
     IGemmArgs a = a_in;
     const int cfg_in = cfg;
     if (stats_row_px) *stats_row_px = 0;
@@ -607,14 +627,11 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                         if (geglu && !kCfg[c].geglu_ok) continue;
                         if (((c >= 7 && c <= 15) || c == 22) && ((a.C0 % 64) || (a.C1 % 64))) continue;
                         if (kCfg[c].bq > 2 * a.Q && kCfg[c].bq > 64) continue;        // grossly oversized in Q
-                        if (kCfg[c].split > 1) {                                        // split-K: few tiles, deep K only
-                            const long long tiles = (long long)((a.Q + kCfg[c].bq - 1) / kCfg[c].bq) * ((a.P + kCfg[c].bp - 1) / kCfg[c].bp);
-                            if (tiles * kCfg[c].split > 1024 || tiles > 256 || (a.K / 64) / kCfg[c].split < 8) continue;
+                        if (kCfg[c].split > 1 && !splitk_admissible(a, c)) continue;    // split-K: few tiles, deep K only
                         }
-                        }
-                        if (ladi_launch_igemm(a, batch, c, st) != 0) continue;          // warm-up (also sets function attributes)
+                        if (ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes) != 0) continue;   // warm-up (also sets function attributes)
                         (void)hipEventRecord(e0, st);
-                        for (int r = 0; r < 3; ++r) (void)ladi_launch_igemm(a, batch, c, st);
+                        for (int r = 0; r < 3; ++r) (void)ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes);
                         (void)hipEventRecord(e1, st);
                         if (hipEventSynchronize(e1) != hipSuccess) continue;
                         float ms = 0.f;
@@ -634,7 +651,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                             float pen = 0.f;
                             if (kCfg[c].base == 23 && a.stats) pen = (float)((double)a.P * a.Q * 2.0 / 3.0e9);
                             (void)hipEventRecord(e0, st);
-                            for (int r = 0; r < 10; ++r) (void)ladi_launch_igemm(a, batch, c, st);
+                            for (int r = 0; r < 10; ++r) (void)ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes);
                             (void)hipEventRecord(e1, st);
                             float ms = 0.f;
                             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
@@ -679,7 +696,11 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     const int split = kCfg[cfg].split;
     if (split > 1) {
         if (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel) return -9;
-        if (!ensure_ws((size_t)split * a.P * a.Q * sizeof(float), st)) return -13;
+        const size_t need = (size_t)split * a.P * a.Q * sizeof(float);
+        if (!ws || ws_bytes < need) {           // no (or too small a) caller slab: process-wide grow-only fallback
+            if (!ensure_ws(need, st)) return -13;
+            ws = g_ws;
+        }
     }
     if (a.stats) {  // fused output statistics need whole 32*TP-pixel row blocks inside one sample
         const int px = (split > 1 ? 1 : kCfg[cfg].tp) * 32;
@@ -697,7 +718,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     IGemmArgs full = a;   // epilogue parameters for the split-K reduce pass
     int lbatch = batch;
     if (split > 1) {
-        a.out = g_ws; a.ldo = a.Q; a.out_f32 = 1; a.bs_out = (long long)a.P * a.Q; a.splitk = split; lbatch = split;
+        a.out = ws; a.ldo = a.Q; a.out_f32 = 1; a.bs_out = (long long)a.P * a.Q; a.splitk = split; lbatch = split;
         a.bias = nullptr; a.rowadd = nullptr; a.act = LADI_ACT_NONE; a.out_scale = 1.f; a.res0 = nullptr; a.res1 = nullptr;
         a.mask = nullptr; a.stats = nullptr;
     } else a.splitk = 1;
@@ -725,7 +746,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         default: rc = -7;
     }
     if (rc == 0 && split > 1) {
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((full.P + 31) / 32), (unsigned)((full.Q + 63) / 64)), dim3(256), 0, st, g_ws, split, full);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((full.P + 31) / 32), (unsigned)((full.Q + 63) / 64)), dim3(256), 0, st, ws, split, full);
         if (hipGetLastError() != hipSuccess) rc = -11;
     }
     if (prof) { (void)hipEventRecord(rec.e1, st); g_recs.push_back(rec); }

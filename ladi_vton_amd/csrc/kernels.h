@@ -7,7 +7,13 @@
 // ---- igemm.hip
 // a.stats (optional): per-channel partial statistics of the output, [ceil(P / px)][Q][2] floats (sum, sumsq) where px =
 // *stats_row_px pixels per row (a multiple of 32 chosen with the tile shape; 0 = not produced, use ladi_launch_gn_partial)
-int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st, int* stats_row_px = nullptr);
+// ws / ws_bytes: caller-owned split-K slab (fp32 partial tiles) of at least ladi_igemm_splitk_ws_bytes(a, batch) bytes; null -> a
+// process-wide grow-only fallback buffer (never freed, so pointers baked into captured graphs stay valid)
+int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st, int* stats_row_px = nullptr, float* ws = nullptr,
+                      size_t ws_bytes = 0);
+// worst-case split-K slab for this problem over every admissible split configuration (0: split-K can never be chosen); depends on
+// the problem shape only, so a planning pass and the real pass allocate identically
+size_t ladi_igemm_splitk_ws_bytes(const IGemmArgs& a, int batch);
 
 // ---- linear_xs.hip: X-stationary kernel for 1x1 layers with K = 320 / 640 (reached through ladi_launch_igemm cfg 23..27)
 bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs);
@@ -75,6 +81,9 @@ struct StepArgs {
     const StepTable* table; int* step_idx;   // device step counter (read, then incremented by the kernel)
     h16* unet_in; int ld_in;        // next UNet input [2B or B][hw][ld_in]; channels 0..3 rewritten
     int cloth_ch0;                  // first cloth channel (27) ; zeroed when table says so (4 channels)
+    // optional per-evaluation trace (parity tests): guided noise prediction and updated latents of evaluation i are written to
+    // trace_*[i][B][hw][4] (fp32) for i < trace_cap; null = off
+    float* trace_eps; float* trace_lat; int trace_cap;
 };
 int ladi_launch_sched_step(const StepArgs& a, hipStream_t st);
 

@@ -261,7 +261,7 @@ struct TryOnInputs {
     int pose_channels;
     const h16 *prompt_embeds, *negative_prompt_embeds; int L;
     const float *noise_cloth, *noise_latents, *noise_masked;
-    int steps; float guidance; int scheduler; float cloth_cond_rate; int no_pose; int use_graph;
+    int steps; float guidance; int scheduler; int cloth_zero_from; int no_pose; int use_graph;
     const float* alphas_cumprod;  // optional [1000] host
 };
 struct TryOn {
@@ -272,6 +272,7 @@ struct TryOn {
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; unsigned long long graph_key = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool ev_valid = false;
     int last_evals = 0;
+    float* trace_eps = nullptr; float* trace_lat = nullptr; int trace_cap = 0;   // caller-owned per-evaluation trace buffers (tests)
     // the legacy NULL stream (torch's default) cannot be captured: work then runs on this internal stream, fenced
     // against the caller's stream with events on entry and exit
     hipStream_t own_stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -283,7 +284,8 @@ struct TryOn {
 
 // scheduler tables (host): builds timesteps + StepTable entries. kind 0 = DDIM, 1 = PNDM(PLMS, skip_prk_steps)
 void default_alphas_cumprod(std::vector<float>& ac);
-void build_step_table(int kind, int steps, const float* alphas_cumprod, float cloth_cond_rate, std::vector<int>& timesteps,
+// cloth_zero_from: first evaluation index that must see zero cloth latents (tryon_pipe.py:718), computed by the caller in float64
+void build_step_table(int kind, int steps, const float* alphas_cumprod, int cloth_zero_from, std::vector<int>& timesteps,
                       std::vector<StepTable>& table);
 
 }  // namespace ladi

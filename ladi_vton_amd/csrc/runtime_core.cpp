@@ -194,7 +194,11 @@ void launch_conv_into(Ctx& c, IGemmArgs& a, Act& out, int cfg) {
     a.out = out.p; a.ldo = out.ld;
     a.stats = (out.st_part && out.ld == out.c) ? out.st_part : nullptr;
     int px = 0;
-    if (!c.dry()) c.check(ladi_launch_igemm(a, 1, cfg, c.st, &px), "igemm");
+    // split-K slab from this handle's planned arena (stack discipline: it lives until the enclosing block releases its mark), so a
+    // captured graph only ever references memory covered by the graph key (arena base)
+    const size_t wsb = ladi_igemm_splitk_ws_bytes(a, 1);
+    float* ws = wsb ? c.alloc_f32(wsb / sizeof(float)) : nullptr;
+    if (!c.dry()) c.check(ladi_launch_igemm(a, 1, cfg, c.st, &px, ws, wsb), "igemm");
     out.st_px = px;
     if (!c.dry() && px == 0) out.st_part = nullptr;
 }
@@ -284,13 +288,13 @@ void default_alphas_cumprod(std::vector<float>& ac) {
     }
 }
 
-void build_step_table(int kind, int steps, const float* ac, float cloth_cond_rate, std::vector<int>& timesteps,
+void build_step_table(int kind, int steps, const float* ac, int cloth_zero_from, std::vector<int>& timesteps,
                       std::vector<StepTable>& table) {
     const int T = 1000;
+    if (steps < 2 || steps > T) throw std::runtime_error("num_inference_steps out of range [2, 1000]");   // ts[steps - 2] below
     const int ratio = T / steps;
     const double final_ac = ac[0];  // set_alpha_to_one = False
     timesteps.clear(); table.clear();
-    const double ccs = (1.0 - (double)cloth_cond_rate) * (double)steps;  // cloth_conditioning_steps
     if (kind == 0) {
         for (int i = steps - 1; i >= 0; --i) timesteps.push_back(i * ratio + 1);
         for (int i = 0; i < steps; ++i) {
@@ -344,7 +348,7 @@ void build_step_table(int kind, int steps, const float* ac, float cloth_cond_rat
     // `if i >= num_inference_steps - cloth_conditioning_steps: cloth = 0` (tryon_pipe.py:718-719), evaluated at the
     // START of evaluation i -> mark entry i-1 so that the step kernel zeroes the cloth channels for evaluation i.
     for (int i = 1; i < (int)table.size(); ++i)
-        if ((double)i >= (double)steps - ccs) table[i - 1].zero_cloth_next = 1;
+        if (i >= cloth_zero_from) table[i - 1].zero_cloth_next = 1;
 }
 
 }  // namespace ladi

@@ -63,9 +63,9 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
     std::vector<float> ac;
     if (in.alphas_cumprod) ac.assign(in.alphas_cumprod, in.alphas_cumprod + 1000); else default_alphas_cumprod(ac);
     std::vector<int> timesteps; std::vector<StepTable> table;
-    build_step_table(in.scheduler, in.steps, ac.data(), in.cloth_cond_rate, timesteps, table);
+    build_step_table(in.scheduler, in.steps, ac.data(), in.cloth_zero_from, timesteps, table);
     const int evals = (int)timesteps.size();
-    const bool cloth_zero_from_start = has_cloth && (0.0 >= (double)in.steps - (1.0 - (double)in.cloth_cond_rate) * in.steps);
+    const bool cloth_zero_from_start = has_cloth && in.cloth_zero_from <= 0;
     last_evals = evals;
 
     if (!d_step) d_step = reinterpret_cast<int*>(pool.alloc(256));
@@ -161,6 +161,7 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
             StepArgs sa; std::memset(&sa, 0, sizeof(sa));
             sa.B = B; sa.hw = hw; sa.cfg = cfgf; sa.guidance = in.guidance; sa.latents = latents; sa.cur_sample = cur_sample; sa.ets = ets;
             sa.table = d_table; sa.step_idx = d_step; sa.unet_in = unet_in.p; sa.ld_in = 64; sa.cloth_ch0 = 9 + pose_ch;
+            sa.trace_eps = trace_eps; sa.trace_lat = trace_lat; sa.trace_cap = trace_cap;
             const size_t mk_loop = arena.mark();
             auto one_step = [&]() {
                 arena.release(mk_loop);
@@ -180,6 +181,8 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
                 key = mix(key, (unsigned long long)(uintptr_t)unet->temb_table); key = mix(key, (unsigned long long)(uintptr_t)unet->mid_xf.kv_cache);
                 key = mix(key, (unsigned long long)(uintptr_t)d_table); key = mix(key, (unsigned long long)(uintptr_t)stats);
                 key = mix(key, (unsigned long long)pose_ch * 7 + has_cloth);
+                key = mix(key, (unsigned long long)(uintptr_t)trace_eps); key = mix(key, (unsigned long long)(uintptr_t)trace_lat);
+                key = mix(key, (unsigned long long)trace_cap);
                 if (!gexec || key != graph_key) {
                     if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
                     if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }

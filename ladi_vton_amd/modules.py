@@ -63,8 +63,9 @@ def _nhwc_buffer(t):
     return out
 
 
-class _Base:
-    dtype = torch.float16
+class _Shim:
+    """the nn.Module housekeeping the unmodified src/inference.py:192-209 performs on every module (`.to(device, dtype=...)`, `.eval()`):
+    no-ops here, the weights already live on the device in the native layout"""
 
     def to(self, *a, **k):
         return self
@@ -72,7 +73,16 @@ class _Base:
     def eval(self):
         return self
 
+    def train(self, mode=True):
+        return self
+
     def half(self):
+        return self
+
+    def float(self):
+        return self
+
+    def requires_grad_(self, requires_grad=False):
         return self
 
     def modules(self):
@@ -80,6 +90,10 @@ class _Base:
 
     def parameters(self):
         return iter(())
+
+
+class _Base(_Shim):
+    dtype = torch.float16
 
     @property
     def device(self):
@@ -118,13 +132,15 @@ class NativeUNet(_Base):
         return None  # attention is always fused (flash-style) in the native kernels
 
     def set_context(self, ehs):
-        key = (ehs.data_ptr(), tuple(ehs.shape), ehs._version, ehs.dtype)
-        if key == self._ctx_key:
+        # the cross-attention K/V projections are step-invariant: skip the upload when the SAME tensor object (kept alive here, so its
+        # id / storage cannot be recycled by the caching allocator) is passed again unmodified
+        key = (id(ehs), ehs._version)
+        if self._ctx_key == key and self._ctx_keepalive is not None and self._ctx_keepalive[0] is ehs:
             return
         e = ehs.to(dtype=torch.float16).contiguous()
         check(self.lib.ladi_unet_set_context(self.h, ptr(e), e.shape[0], e.shape[1], stream_ptr()), "ladi_unet_set_context")
         self._ctx_key = key
-        self._ctx_keepalive = e
+        self._ctx_keepalive = (ehs, e)
 
     def __call__(self, sample, timestep, encoder_hidden_states=None, **kw):
         if encoder_hidden_states is None:

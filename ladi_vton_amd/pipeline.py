@@ -7,6 +7,7 @@ Two execution modes with identical semantics:
 """
 import ctypes
 import inspect
+import math
 from types import SimpleNamespace
 
 import numpy as np
@@ -38,6 +39,7 @@ class StableDiffusionTryOnePipeline:
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
         self._tryon = None
         self.last_stage_ms = None
+        self.trace_evals = 0          # > 0: the next fused runs record per-evaluation noise_pred / latents into self.last_trace
 
     def to(self, *a, **k):
         return self
@@ -175,10 +177,23 @@ class StableDiffusionTryOnePipeline:
                 raise _lib.NativeError("ladi_tryon_create failed: " + _lib.last_error())
         dev = self._execution_device
         dt = torch.float16 if image.dtype == torch.float16 else torch.float32
+        B = pe.shape[0]
+        # the C ABI takes raw device pointers: every shape the kernels assume is checked here (the reference fails in torch.cat at
+        # tryon_pipe.py:724-729 for the same mistakes)
+        h8, w8 = H // 8, W // 8
+        for name, t, shp in (("image", image, (B, 3, H, W)), ("mask_image", mask_image, (B, 1, H, W)),
+                             ("warped_cloth", cloth, (B, 3, H, W)), ("cloth posterior noise", n_cloth, (B, 4, h8, w8)),
+                             ("latents", n_lat, (B, 4, h8, w8)), ("masked-image posterior noise", n_mask, (B, 4, h8, w8))):
+            if t is not None and tuple(t.shape) != shp:
+                raise ValueError("%s has shape %s, expected %s (batch from prompt_embeds, size from height/width)" % (name, tuple(t.shape), shp))
+        if pose_map.dim() != 4 or pose_map.shape[0] != B or tuple(pose_map.shape[2:]) != (H, W):
+            raise ValueError("pose_map has shape %s, expected (%d, P, %d, %d)" % (tuple(pose_map.shape), B, H, W))
+        if neg is not None and tuple(neg.shape) != tuple(pe.shape):
+            raise ValueError("negative_prompt_embeds shape %s != prompt_embeds shape %s" % (tuple(neg.shape), tuple(pe.shape)))
         keep = [t.to(device=dev, dtype=dt).contiguous() if t is not None else None for t in (image, mask_image, pose_map, cloth)]
         pe16 = pe.to(device=dev, dtype=torch.float16).contiguous()
         neg16 = neg.to(device=dev, dtype=torch.float16).contiguous() if neg is not None else None
-        B = pe16.shape[0]
+        n_cloth, n_lat, n_mask = [t.to(device=dev, dtype=torch.float32).contiguous() if t is not None else None for t in (n_cloth, n_lat, n_mask)]
         inp = TryOnInputs()
         inp.batch, inp.height, inp.width, inp.in_dtype = B, H, W, dtype_code(keep[0])
         inp.image_dev, inp.mask_image_dev, inp.pose_map_dev = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
@@ -191,12 +206,26 @@ class StableDiffusionTryOnePipeline:
         inp.noise_latents_dev, inp.noise_masked_dev = n_lat.data_ptr(), n_mask.data_ptr()
         inp.num_inference_steps, inp.guidance_scale = int(steps), float(guidance)
         inp.scheduler = self.scheduler.kind
-        inp.cloth_cond_rate, inp.no_pose, inp.use_graph = float(ccr), int(bool(no_pose)), int(bool(use_graph))
+        # tryon_pipe.py:654,718 in the reference's own float64 arithmetic: first evaluation index i with i >= steps - (1 - rate) * steps
+        ccs = (1 - ccr) * steps
+        inp.cloth_zero_from_eval = min(max(0, math.ceil(steps - ccs)), 1 << 30)
+        inp.no_pose, inp.use_graph = int(bool(no_pose)), int(bool(use_graph))
         ac = self.scheduler.alphas_cumprod.to("cpu", torch.float32).contiguous()
         inp.alphas_cumprod_host = ac.data_ptr()
         images = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
         self.last_latents = torch.empty((B, 4, H // 8, W // 8), dtype=torch.float32, device=dev)
+        tr = None
+        if self.trace_evals > 0:
+            tr = torch.zeros((2, self.trace_evals, B, h8 * w8, 4), dtype=torch.float32, device=dev)
+            check(lib.ladi_tryon_set_trace(self._tryon, ptr(tr[0]), ptr(tr[1]), self.trace_evals), "ladi_tryon_set_trace")
+        else:
+            check(lib.ladi_tryon_set_trace(self._tryon, None, None, 0), "ladi_tryon_set_trace")
+        # the fused loop rewrites the UNet's cross-attention K/V cache behind the shim's back
+        self.unet._ctx_key = None
         check(lib.ladi_tryon_run(self._tryon, ctypes.byref(inp), ptr(images), ptr(self.last_latents), stream_ptr()), "ladi_tryon_run")
+        if tr is not None:   # [evals, B, 4, h, w] like the reference's noise_pred / latents (tryon_pipe.py:732-740)
+            nchw = tr.view(2, self.trace_evals, B, h8, w8, 4).permute(0, 1, 2, 5, 3, 4)
+            self.last_trace = dict(noise_pred=nchw[0].contiguous(), latents=nchw[1].contiguous())
         if return_device:
             return images
         out = images.cpu().numpy()  # the reference's only sync point (tryon_pipe.py:358)

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import NativeError, TextConfig, check, ptr, stream_ptr
-from .modules import _Weights
+from .modules import _Shim, _Weights
 
 
 class TextEncoderOutput:
@@ -27,7 +27,7 @@ class TextEncoderOutput:
         return (self.last_hidden_state, self.pooler_output)[i]
 
 
-class NativeCLIPTextEncoder:
+class NativeCLIPTextEncoder(_Shim):
     """holds the text-encoder weights on the device (fp16) behind a ladi_text_encoder handle"""
 
     def __init__(self, cfg, state_dict):

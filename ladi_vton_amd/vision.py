@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import NativeError, VisionConfig, check, dtype_code, ptr, stream_ptr
-from .modules import _Weights
+from .modules import _Shim, _Weights
 
 
 class VisionEncoderOutput:
@@ -26,7 +26,7 @@ class VisionEncoderOutput:
         return (self.last_hidden_state, self.pooler_output)[i]
 
 
-class NativeCLIPVisionEncoder:
+class NativeCLIPVisionEncoder(_Shim):
     def __init__(self, cfg, state_dict):
         _lib.require_gpu()
         self.lib = _lib.load()

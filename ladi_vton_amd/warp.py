@@ -15,10 +15,10 @@ import torch
 
 from . import _lib
 from ._lib import NativeError, RefineConfig, TpsConfig, check, dtype_code, ptr, stream_ptr
-from .modules import _Weights
+from .modules import _Shim, _Weights
 
 
-class NativeRefinementUNet:
+class NativeRefinementUNet(_Shim):
     def __init__(self, cfg, state_dict):
         _lib.require_gpu()
         self.lib = _lib.load()
@@ -55,7 +55,7 @@ class NativeRefinementUNet:
         return out
 
 
-class NativeTPS:
+class NativeTPS(_Shim):
     def __init__(self, cfg, state_dict):
         _lib.require_gpu()
         self.lib = _lib.load()

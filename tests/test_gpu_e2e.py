@@ -1,0 +1,102 @@
+"""End-to-end parity ON THE BASELINE CONFIGURATION: the full-size model (released
+architecture, deterministic synthetic checkpoint) at 512x384 through the fused hipGraph loop for 50 PNDM (51 evaluations) and
+50 DDIM steps at B = 1, against the CPU fp32 oracle on identical fp16-rounded weights / inputs / noise, with a per-evaluation trace.
+
+Stated tolerances: single UNet forward PSNR >= 60 dB (peak = max|ref|) and rel-L2 <= 2e-3; decoded image after
+50 steps >= 35 dB on [0,1] images.  Every measured value is also written to gpurun_out/parity_r02.json (copied to profiles/)."""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+from oracle import configs as C
+from oracle import models as M
+from oracle import pipeline as P
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(key, value):
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "parity_r02.json")
+        blob = json.load(open(path)) if os.path.exists(path) else {}
+        blob[key] = value
+        json.dump(blob, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope="module")
+def full():
+    import ladi_vton_amd as L
+    torch.set_num_threads(U.cpu_quota_threads())
+    ucfg, vcfg, ecfg = C.UNET_FULL, C.VAE_FULL, C.EMASC_FULL
+    sd = dict(unet=C.synth_state_dict(C.unet_shapes(ucfg), "unet."), vae=C.synth_state_dict(C.vae_shapes(vcfg), "vae."),
+              emasc=C.synth_state_dict(C.emasc_shapes(ecfg), "emasc."))
+    mod = dict(unet=L.NativeUNet(ucfg, sd["unet"]), vae=L.NativeVAE(vcfg, sd["vae"]), emasc=L.NativeEMASC(ecfg, sd["emasc"]))
+    return dict(ucfg=ucfg, vcfg=vcfg, ecfg=ecfg, sd=sd, mod=mod)
+
+
+def test_full_unet_single_forward_stated_tolerance(full):
+    """noise_pred of ONE full-size CFG evaluation at 64x48: the stated contract is PSNR >= 60 dB and rel-L2 <= 2e-3"""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 31, 64, 48), generator=g).half().float()
+    ehs = torch.randn((2, 77, 1024), generator=g).half().float()
+    vals = {}
+    for t in (981, 501, 1):
+        ref = M.unet_forward(full["sd"]["unet"], full["ucfg"], x, t, ehs)
+        got = full["mod"]["unet"](x.to(U.dev()), t, encoder_hidden_states=ehs.to(U.dev())).sample.float().cpu()
+        vals[str(t)] = dict(psnr_db=round(U.psnr(got, ref), 2), rel_l2=U.rel_l2(got, ref))
+    _record("unet_forward_full_64x48", vals)
+    for t, v in vals.items():
+        assert v["psnr_db"] >= 60.0 and v["rel_l2"] <= 2e-3, (t, v)
+
+
+@pytest.mark.parametrize("sched", ["pndm", "ddim"])
+def test_baseline_config_50_steps_vs_oracle(full, sched):
+    """BASELINE configs[1] arithmetic at B = 1: 512x384, 50 scheduler steps (PNDM: 51 UNet evaluations), guidance 7.5, EMASC on"""
+    import ladi_vton_amd as L
+    B, H, W, steps = 1, 512, 384, 50
+    inp = P.synthetic_inputs(B, H, W, L=77, D=1024)
+    for k in ("prompt_embeds", "negative_prompt_embeds"):
+        inp[k] = inp[k].half().float()
+    trace = {}
+    t0 = time.time()
+    ref_img, ref_lat = P.tryon_pipeline(full["sd"]["unet"], full["ucfg"], full["sd"]["vae"], full["vcfg"], full["sd"]["emasc"], inp,
+                                        num_inference_steps=steps, guidance_scale=7.5, scheduler=sched, trace=trace)
+    cpu_s = time.time() - t0
+    sch = L.DDIMScheduler() if sched == "ddim" else L.PNDMScheduler()
+    pipe = L.StableDiffusionTryOnePipeline(vae=full["mod"]["vae"], text_encoder=None, tokenizer=None, unet=full["mod"]["unet"], scheduler=sch,
+                                           emasc=full["mod"]["emasc"], emasc_int_layers=[1, 2, 3, 4, 5])
+    evals = steps + 1 if sched == "pndm" else steps
+    pipe.trace_evals = evals
+    d = U.dev()
+    out = pipe(image=inp["image"].to(d), mask_image=inp["mask_image"].clone().to(d), pose_map=inp["pose_map"].to(d),
+               warped_cloth=inp["warped_cloth"].to(d), prompt_embeds=inp["prompt_embeds"].to(d),
+               negative_prompt_embeds=inp["negative_prompt_embeds"].to(d), height=H, width=W, num_inference_steps=steps,
+               guidance_scale=7.5, output_type="np", fused=True, use_graph=True,
+               noise=(inp["noise_cloth"], inp["noise_latents"], inp["noise_masked"]))
+    img = torch.from_numpy(out.images)
+    lat = pipe.last_latents.float().cpu()
+    tr = {k: v.cpu() for k, v in pipe.last_trace.items()}
+    assert len(trace["noise_pred"]) == evals and tr["noise_pred"].shape[0] == evals
+    eps_psnr = [round(U.psnr(tr["noise_pred"][i], trace["noise_pred"][i]), 2) for i in range(evals)]
+    lat_psnr = [round(U.psnr(tr["latents"][i], trace["latents"][i]), 2) for i in range(evals)]
+    u8a, u8b = (img * 255).round(), (ref_img * 255).round()
+    res = dict(evals=evals, image_psnr_db=round(U.psnr(img, ref_img, 1.0), 2), final_latents_psnr_db=round(U.psnr(lat, ref_lat), 2),
+               uint8_psnr_db=round(U.psnr(u8a, u8b, 255.0), 2), uint8_max_abs_diff=int((u8a - u8b).abs().max()),
+               noise_pred_psnr_db_per_eval=eps_psnr, latents_psnr_db_per_eval=lat_psnr,
+               noise_pred_psnr_db_min=min(eps_psnr), latents_psnr_db_min=min(lat_psnr), cpu_oracle_seconds=round(cpu_s, 1),
+               cpu_threads=torch.get_num_threads())
+    _record("tryon_512x384_50_%s_B1" % sched, res)
+    assert img.shape == ref_img.shape == (B, H, W, 3)
+    assert torch.equal(tr["latents"][-1], lat)                                     # the trace really is this run's trajectory
+    assert res["image_psnr_db"] >= 35.0, res                                       # full pipeline after 50 steps
+    assert res["final_latents_psnr_db"] >= 35.0 and res["noise_pred_psnr_db_min"] >= 35.0, res
+    assert eps_psnr[0] >= 55.0, eps_psnr[:3]                                       # first evaluation: no accumulated trajectory error yet

@@ -415,3 +415,95 @@ def test_scheduler_device_vs_oracle(lib, kind, steps):
     assert rc == 0, _lib.last_error()
     torch.cuda.synchronize()
     assert U.rel_l2(L.cpu(), x) < 1e-5
+
+
+# --------------------------------------------------------------------------------------------------------------- pipeline pre-processing (§8 a10)
+@pytest.mark.parametrize("f16", [False, True])
+def test_prepare_mask_and_masked_image(lib, f16):
+    """diffusers prepare_mask_and_masked_image tensor branch (tryon_pipe.py:630): binarise at 0.5, masked = image * (mask < 0.5); exact"""
+    B, H, W = 2, 40, 24
+    g = torch.Generator().manual_seed(60)
+    img = (torch.rand((B, 3, H, W), generator=g) * 2 - 1).half().float()
+    mask = torch.rand((B, 1, H, W), generator=g).half().float()
+    mask[0, 0, 0, :4] = torch.tensor([0.5, 0.4999, 0.0, 1.0]).half().float()      # threshold edge: 0.5 -> 1
+    dt = torch.float16 if f16 else torch.float32
+    I, Mk = img.to(U.dev(), dt), mask.to(U.dev(), dt)
+    masked = torch.full((B, H, W, 64), 7.0, dtype=torch.float16, device=U.dev())
+    mbin = torch.empty((B, H, W), dtype=torch.float16, device=U.dev())
+    assert lib.ladi_op_prepare_mask(ptr(I), ptr(Mk), 1 if f16 else 0, B, H, W, ptr(masked), 64, ptr(mbin), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    ref_bin = (mask >= 0.5).float()
+    assert torch.equal(mbin.float().cpu(), ref_bin[:, 0])
+    assert torch.equal(masked[..., :3].float().cpu(), (img * (ref_bin < 0.5)).permute(0, 2, 3, 1))
+    assert float(masked[..., 3:].abs().max()) == 0.0                              # padding channels zeroed
+
+
+@pytest.mark.parametrize("s", [2, 4, 8])
+def test_mask_down_is_nearest_interpolate(lib, s):
+    """F.interpolate(mask, size=(H/s, W/s)) (nearest: source pixel floor(i * s)) — prepare_mask_latents :424-427 and mask_features; exact"""
+    B, H, W = 2, 64, 48
+    m = (torch.rand((B, 1, H, W), generator=torch.Generator().manual_seed(61)) > 0.5).float()
+    out = torch.empty((B, H // s, W // s), dtype=torch.float16, device=U.dev())
+    assert lib.ladi_op_mask_down(ptr(m[:, 0].half().contiguous().to(U.dev())), B, H, W, s, ptr(out), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu(), F.interpolate(m, size=(H // s, W // s))[:, 0])
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_pose_down8_is_bilinear_interpolate(lib, f16):
+    """F.interpolate(pose_map, size=(H/8, W/8), mode='bilinear') (tryon_pipe.py:632-634): fp32 arithmetic, fp16 result"""
+    B, C, H, W = 2, 18, 64, 48
+    p = torch.rand((B, C, H, W), generator=torch.Generator().manual_seed(62)).half().float()
+    Pd = p.to(U.dev(), torch.float16 if f16 else torch.float32)
+    out = torch.empty((B, (H // 8) * (W // 8), C), dtype=torch.float16, device=U.dev())
+    assert lib.ladi_op_pose_down8(ptr(Pd), 1 if f16 else 0, B, C, H, W, ptr(out), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    ref = F.interpolate(p, size=(H // 8, W // 8), mode="bilinear").permute(0, 2, 3, 1).reshape(B, -1, C)
+    assert (out.float().cpu() - ref).abs().max() <= 1e-3 and U.rel_l2(out.float().cpu(), ref) <= 5e-4
+
+
+def test_posterior_sample(lib):
+    """sf * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) (vae.py:329-348), incl. the clamp on both sides; rel <= 1e-5 (fp32)"""
+    from oracle import models as M
+    B, h, w = 2, 8, 6
+    g = torch.Generator().manual_seed(63)
+    mom = torch.randn((B, 8, h, w), generator=g)
+    mom[0, 4, 0, 0], mom[0, 5, 0, 0], mom[1, 6, 1, 1] = 40.0, -50.0, 19.5      # clamp at 20 / -30, and an un-clamped large value
+    mom = mom.half().float()
+    noise = torch.randn((B, 4, h, w), generator=g)
+    mm = torch.zeros((B, h * w, 64), dtype=torch.float16)
+    mm[..., :8] = mom.permute(0, 2, 3, 1).reshape(B, h * w, 8).half()
+    lat = torch.empty((B, h * w, 4), dtype=torch.float32, device=U.dev())
+    assert lib.ladi_op_posterior_sample(ptr(mm.to(U.dev())), 64, ptr(noise.to(U.dev())), B, h * w, 0.18215, ptr(lat), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    ref = (0.18215 * M.posterior_sample(mom, noise)).permute(0, 2, 3, 1).reshape(B, h * w, 4)
+    assert U.rel_l2(lat.cpu(), ref) <= 1e-5
+
+
+@pytest.mark.parametrize("cfg,cloth", [(1, True), (0, True), (1, False)])
+def test_assemble_unet_input(lib, cfg, cloth):
+    """31-channel order [latents | mask | masked latents | pose | cloth] and CFG batch order [uncond; cond] with zero pose / cloth in the
+    uncond half (tryon_pipe.py:702-729); exact up to the fp16 cast of the fp32 latents"""
+    B, hw, P_ = 2, 24, 18
+    g = torch.Generator().manual_seed(64)
+    lat, mlat, clat = [torch.randn((B, hw, 4), generator=g) for _ in range(3)]
+    mask = (torch.rand((B, hw), generator=g) > 0.5).half()
+    pose = torch.rand((B, hw, P_), generator=g).half()
+    n = 2 * B if cfg else B
+    out = torch.full((n, hw, 64), 3.0, dtype=torch.float16, device=U.dev())
+    d = U.dev()
+    keep = [lat.to(d), mask.to(d), mlat.to(d), pose.to(d), clat.to(d)]
+    assert lib.ladi_op_assemble_input(ptr(out), 64, B, hw, cfg, ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), P_,
+                                      ptr(keep[4]) if cloth else None, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    parts = [lat.half(), mask[..., None], mlat.half(), pose] + ([clat.half()] if cloth else [])
+    cond = torch.cat(parts, dim=-1)
+    C = cond.shape[-1]
+    assert C == (31 if cloth else 27)
+    got = out.cpu()
+    if cfg:
+        unc = cond.clone(); unc[..., 9:] = 0
+        assert torch.equal(got[:B, :, :C], unc) and torch.equal(got[B:, :, :C], cond)
+    else:
+        assert torch.equal(got[..., :C], cond)
+    assert float(got[..., C:].abs().max()) == 0.0
