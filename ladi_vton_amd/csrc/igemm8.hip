@@ -1,0 +1,230 @@
+// Phase-staggered 8-wave large-tile implicit GEMM (the "8-phase" pipeline), reached through ladi_launch_igemm (cfg 32..38).
+#include "common.h"
+#include "kernels.h"
+#include "igemm_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// igemm8_kernel: the large-tile kernel.  Same operand orientation, LDS image, swizzle, K order and epilogue as igemm_kernel, but
+// the K loop is a PHASE-STAGGERED pipeline (cdna_hip_programming.md §5 "256^2 8-phase template", T3+T4+T5):
+//   * 8 waves = 2 channel groups x 4 pixel columns; wave tile (TQ*32) x (TP*32); workgroup tile BQ = 64*TQ, BP = 128*TP; BK = 64;
+//     one workgroup per CU, two K-tile buffers of (BQ + BP) x 128 B.
+//   * a K tile is consumed in TQ phases; phase q multiplies the wave's q-th 32-channel block with its whole pixel strip
+//     (4*TP MFMAs).  A phase = load segment {ds_read the fragments of this phase; issue this phase's share of the LDS-DMA pieces of
+//     the NEXT K tile; counted vmcnt; lgkmcnt(0)} -> s_barrier -> MFMA segment (s_setprio 1) -> s_barrier.
+//   * the two channel groups (waves 0-3 / 4-7; one wave of each on every SIMD) run ONE barrier apart, so on every SIMD one wave is
+//     in its MFMA segment while its partner issues LDS reads and DMA: the matrix pipe never waits for the load path, and
+//     s_setprio has something to arbitrate.
+//   * staging granule ("piece") = 64 tile rows x 128 B = one 16-byte LDS-DMA per thread.  Pieces of K tile kt+1 are issued during
+//     K tile kt in the order they are needed (pixel pieces, then channel block 0, 1, ...), a few per phase; vmcnt is never 0 in the
+//     loop: at the end of load segment q the wave waits only for ITS pieces that phase q+1 reads (count derived below), and the
+//     barrier that follows publishes them.  Every wave retires its own ds_reads (lgkmcnt 0) before each barrier, so a region may be
+//     re-staged as soon as the barrier after its last reading phase has been passed.
+// Hazard table (interval k = between barrier k and k+1; global phase p = kt*TQ + q; G0 / G1 = channel group 0 / 1):
+//   G0: load(p) in interval 2p-1, mfma(p) in 2p.   G1: load(p) in interval 2p, mfma(p) in 2p+1.
+//   RAW  piece needed by load(p+1): every wave waits for its own DMAs of it in load(p) (G0: interval 2p-1, G1: 2p), i.e. before
+//        barrier 2p+1; the earliest reader is G0's load(p+1) in interval 2p+1.
+//   WAR  region A(kt, q) is last read in interval 2p (G1) and re-staged with A(kt+2, q) during K tile kt+1 (>= interval 2p+2TQ-3... always
+//        later than barrier 2p+1 because pieces of kt+2 are only issued from G0's load(kt+1, 0) on, interval 2(kt+1)TQ-1 >= 2p+1).
+//        region B(kt) is last read in interval 2*kt*TQ and re-staged from interval 2(kt+1)TQ-1 on.
+// ------------------------------------------------------------------------------------------------
+template <int TQ, int TP>
+__global__ __launch_bounds__(512, 2) void igemm8_kernel(const IGemmArgs a) {
+    constexpr int WQ = 2, WP = 4, BK = 64;
+    constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
+    constexpr int NB = BP / 64;            // pixel pieces per K tile
+    constexpr int NA = TQ;                 // channel pieces per K tile: piece q = [group 0 block q (32 rows) | group 1 block q]
+    constexpr int NPIECE = NA + NB;
+    constexpr int PPP = (NPIECE + TQ - 1) / TQ;   // pieces issued per phase
+    constexpr int BUF = (BQ + BP) * BK * 2;       // bytes per K-tile buffer
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    h16* smem = reinterpret_cast<h16*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
+    int qt, pt;
+    {
+        const int b = blockIdx.x;
+        if (a.tile_map == 1) {
+            const int npx = (np + 7) >> 3, xcd = b & 7, loc = b >> 3;
+            pt = xcd * npx + loc / nq; qt = loc % nq;
+            if (pt >= np) return;
+        } else if (a.tile_map == 2) {
+            const int nqx = (nq + 7) >> 3, xcd = b & 7, loc = b >> 3;
+            qt = xcd * nqx + loc / np; pt = loc % np;
+            if (qt >= nq) return;
+        } else { qt = b % nq; pt = b / nq; }
+    }
+    const int q0 = qt * BQ, p0 = pt * BP;
+    const int z = blockIdx.z;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wq = wave >> 2, wp = wave & 3;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int r0 = tid >> 3;                          // row of this thread inside a 64-row piece
+    const int clog = (tid & 7) ^ ((r0 >> 1) & 7);     // logical 16-byte chunk its DMA fetches (swizzle on the source side)
+
+    const int HoWo = a.Ho * a.Wo;
+    const int HsWs = a.Hs * a.Ws;
+    const int n_first = p0 / HoWo;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.src0 + (a.splitk > 1 ? 0 : (size_t)z * a.bs_src0) + (size_t)n_first * HsWs * a.ld0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.src1 ? a.src1 + (size_t)n_first * HsWs * a.ld1 : a.src0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.W + (a.splitk > 1 ? 0 : (size_t)z * a.bs_w)), 0, 0x7FFFFFFF, 0x00020000);
+
+    const int Hlog = a.ups ? 2 * a.Hs : a.Hs;
+    const int Wlog = a.ups ? 2 * a.Ws : a.Ws;
+    int nb[NB], iy0[NB], ix0[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int p = p0 + r0 + 64 * i;
+        const bool ok = p < a.P;
+        const int pp = ok ? p : 0;
+        const int n = pp / HoWo;
+        const int rem = pp - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        iy0[i] = ok ? (oy * a.stride - a.pad) : -100000;
+        ix0[i] = ox * a.stride - a.pad;
+        nb[i] = (n - n_first) * HsWs;
+    }
+    const int Ct = a.C0 + a.C1;
+    const int ldw = a.ldw ? a.ldw : a.K;
+    unsigned wbase[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int q = q0 + (r0 >> 5) * (TQ * 32) + i * 32 + (r0 & 31);
+        wbase[i] = (q < a.Q) ? (unsigned)(((size_t)q * ldw + clog * 8) * 2) : OOB;
+    }
+
+    int nk = a.K / BK;
+    const int ntap = a.ksize * a.ksize;
+    int tap = 0, cb = 0;   // (tap, channel base) of the K tile being STAGED
+    if (a.splitk > 1) {
+        const int sps = (nk + a.splitk - 1) / a.splitk;
+        const int start = z * sps;
+        nk = max(0, min(sps, nk - start));
+        cb = (start / ntap) * BK; tap = start - (start / ntap) * ntap;
+    }
+    int tdy = tap / a.ksize, tdx = tap - (tap / a.ksize) * a.ksize;
+    bool st_valid = nk > 0;            // the K tile being staged exists (tail pieces are issued out of range: zeros, same vmcnt cadence)
+
+    // one piece of the K tile described by (tap, cb, tdy, tdx) into buffer `buf`
+    auto issue_piece = [&](auto IC, char* buf) {
+        constexpr int i = decltype(IC)::value;
+        if constexpr (i < NB) {
+            const bool s0 = cb < a.C0;
+            const __amdgpu_buffer_rsrc_t rs = s0 ? rs0 : rs1;
+            const int ld = s0 ? a.ld0 : a.ld1;
+            const int c = (s0 ? cb : cb - a.C0) + clog * 8;
+            int iy = iy0[i] + tdy, ix = ix0[i] + tdx;
+            const bool ok = st_valid && ((unsigned)iy < (unsigned)Hlog) && ((unsigned)ix < (unsigned)Wlog);
+            if (a.ups) { iy >>= 1; ix >>= 1; }
+            const unsigned vo = ok ? (unsigned)(((nb[i] + iy * a.Ws + ix) * ld + c) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(buf + BQ * BK * 2 + i * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+        } else {
+            constexpr int q = i - NB;
+            const int k0 = tap * Ct + cb;
+            const unsigned vo = (wbase[q] == OOB || !st_valid) ? OOB : wbase[q] + (unsigned)(k0 * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(buf + q * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+    auto advance_stage = [&](int kt_staged_next) {
+        if (++tdx == a.ksize) { tdx = 0; ++tdy; }
+        if (++tap == ntap) { tap = 0; tdy = 0; tdx = 0; cb += BK; }
+        st_valid = kt_staged_next < nk;
+    };
+
+    f32x16 acc[TQ][TP];
+#pragma unroll
+    for (int i = 0; i < TQ; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: the whole of K tile 0 in need order; pixel pieces + channel block 0 must have landed before the first phase
+    static_for<0, NPIECE>([&](auto IC) { issue_piece(IC, smem_raw); });
+    advance_stage(1);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NA - 1) : "memory");
+    if (wq == 1) asm volatile("s_barrier" ::: "memory");          // channel group 1 runs one barrier behind
+
+    h16x8 bf[TP][4];
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem_raw + (kt & 1) * BUF;
+        char* nxt = smem_raw + ((kt + 1) & 1) * BUF;
+        const h16* sW = reinterpret_cast<const h16*>(cur);
+        const h16* sX = sW + BQ * BK;
+        static_for<0, TQ>([&](auto QC) {
+            constexpr int q = decltype(QC)::value;
+            // ---------------- load segment
+            h16x8 af[4];
+            if constexpr (q == 0) {
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        bf[j][kk] = *reinterpret_cast<const h16x8*>(sX + swz<64>((wp * TP + j) * 32 + l31, kk * 2 + hh));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                af[kk] = *reinterpret_cast<const h16x8*>(sW + swz<64>(q * 64 + wq * 32 + l31, kk * 2 + hh));
+            static_for<q * PPP, ((q + 1) * PPP < NPIECE ? (q + 1) * PPP : NPIECE)>([&](auto IC) { issue_piece(IC, nxt); });
+            // pieces this wave has issued AFTER the last piece that phase q+1 reads (in-order completion): see the header comment
+            constexpr int issued_next = ((q + 1) * PPP < NPIECE ? (q + 1) * PPP : NPIECE);
+            constexpr int N = (q + 1 < TQ) ? (NPIECE - 1 - (NB + q + 1)) + issued_next : (NA - 1);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+            // ---------------- MFMA segment
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[j][kk], acc[q][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+        });
+        advance_stage(kt + 2);
+    }
+    if (wq == 0) asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tail pieces (zeros) must not land in the epilogue's patches
+
+    igemm_epilogue<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane);
+}
+
+template <int TQ, int TP>
+int launch_cfg8(IGemmArgs a, int batch, hipStream_t st) {
+    constexpr int BQ = 64 * TQ, BP = 128 * TP;
+    constexpr int SMEM = 2 * (BQ + BP) * 64 * (int)sizeof(h16);
+    static bool attr_set = false;
+    auto kfn = igemm8_kernel<TQ, TP>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+            return -10;
+        attr_set = true;
+    }
+    const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
+    int blocks = nq * np;
+    a.tile_map = 0;
+    if (batch == 1 || a.splitk > 1) {
+        if (np >= 16) { a.tile_map = 1; blocks = 8 * ((np + 7) / 8) * nq; }
+        else if (nq >= 16) { a.tile_map = 2; blocks = 8 * ((nq + 7) / 8) * np; }
+    }
+    dim3 grid((unsigned)blocks, 1, (unsigned)batch);
+    hipLaunchKernelGGL(kfn, grid, dim3(512), SMEM, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+}  // namespace
+
+int ladi_launch_igemm8(const IGemmArgs& a, int tq, int tp, int batch, hipStream_t st) {
+    if (tq == 5 && tp == 2) return launch_cfg8<5, 2>(a, batch, st);
+    if (tq == 4 && tp == 2) return launch_cfg8<4, 2>(a, batch, st);
+    return -7;
+}

@@ -15,6 +15,10 @@ int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st, in
 // the problem shape only, so a planning pass and the real pass allocate identically
 size_t ladi_igemm_splitk_ws_bytes(const IGemmArgs& a, int batch);
 
+// ---- igemm8.hip: phase-staggered 8-wave large-tile kernel, wave tile (tq*32 channels) x (tp*32 pixels); a.splitk / a.tile_map as set by
+// ladi_launch_igemm, which is the only caller
+int ladi_launch_igemm8(const IGemmArgs& a, int tq, int tp, int batch, hipStream_t st);
+
 // ---- linear_xs.hip: X-stationary kernel for 1x1 layers with K = 320 / 640 (reached through ladi_launch_igemm cfg 23..27)
 bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs);
 int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st);

@@ -97,6 +97,9 @@ def test_baseline_config_50_steps_vs_oracle(full, sched):
     _record("tryon_512x384_50_%s_B1" % sched, res)
     assert img.shape == ref_img.shape == (B, H, W, 3)
     assert torch.equal(tr["latents"][-1], lat)                                     # the trace really is this run's trajectory
-    assert res["image_psnr_db"] >= 35.0, res                                       # full pipeline after 50 steps
-    assert res["final_latents_psnr_db"] >= 35.0 and res["noise_pred_psnr_db_min"] >= 35.0, res
+    # SURVEY.md §8d contract: full pipeline after 50 steps >= 35 dB.  Measured on MI355X (profiles/r02_parity.json): image 63.6 / 64.1 dB,
+    # final latents 66.3 / 66.9 dB, guided noise_pred >= 55.5 dB at every evaluation, uint8 max abs diff 1 -> regression guards:
+    assert res["image_psnr_db"] >= 50.0, res
+    assert res["final_latents_psnr_db"] >= 55.0 and res["noise_pred_psnr_db_min"] >= 50.0, res
+    assert res["uint8_max_abs_diff"] <= 2, res
     assert eps_psnr[0] >= 55.0, eps_psnr[:3]                                       # first evaluation: no accumulated trajectory error yet

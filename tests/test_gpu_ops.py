@@ -21,7 +21,7 @@ def _rand(shape, seed, scale=1.0):
 
 
 # --------------------------------------------------------------------------------------------------------------- igemm
-@pytest.mark.parametrize("cfg", [19, 20, 21, 22])
+@pytest.mark.parametrize("cfg", [19, 20, 21, 22, 32, 33])
 def test_conv3x3_eight_wave_tiles(cfg):
     """8-wave (512-thread) workgroup tile shapes, ragged pixel count, residual + statistics-free epilogue"""
     N, cin, cout, h, w = 3, 128, 320, 20, 13
@@ -96,7 +96,7 @@ def test_linear_x_stationary_rejects_unsupported():
         U.igemm(U.nhwc16(x), U.pack_conv_weight(w), 320, ksize=1, act="silu", cfg=25)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 16, 17, 18, 19, 20, 21, 22])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 16, 17, 18, 19, 20, 21, 22, 32, 33])
 def test_mfma_layout_asymmetric(cfg):
     """transpose-detecting check of the MFMA fragment / accumulator mapping: 1x1 'conv' with an asymmetric weight."""
     N, H, W, C, Q = 1, 16, 24, 64, 192
@@ -121,7 +121,7 @@ def test_conv3x3_bias_res_temb(cin, cout, h, w, cfg):
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 34, 35, 36, 37, 38])
 def test_conv3x3_split_k(cfg):
     """split-K variants (fp32 partial slices + reduce pass that applies the epilogue) on a few-tile / deep-K problem"""
     N, cin, cout, h, w = 2, 512, 192, 8, 6
@@ -130,6 +130,46 @@ def test_conv3x3_split_k(cfg):
     ref = F.silu(F.conv2d(x, wt, b, padding=1) + temb[None, :, None, None]) + res
     y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cout, bias=b, rowadd=temb, act="silu", res0=U.nhwc16(res), cfg=cfg)
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
+
+
+@pytest.mark.parametrize("cfg", [32, 33])
+def test_igemm8_staggered_pipeline_shapes(cfg):
+    """the phase-staggered large-tile kernel (igemm8.hip) on every gather variant and K-loop length it has to pipeline: a single K tile
+    (prologue only), odd / even K-tile counts, two-source concat, stride 2, folded 2x upsample, ragged pixel and channel tiles"""
+    # 1x1, K = 64: one K tile; K = 192: three
+    for cin, cout, hw in ((64, 96, (9, 7)), (192, 320, (24, 16)), (128, 700, (40, 13))):
+        x, w, b = _rand((2, cin) + hw, 80), _rand((cout, cin, 1, 1), 81, 1 / math.sqrt(cin)), _rand((cout,), 82, 0.1)
+        y = U.igemm(U.nhwc16(x), U.pack_conv_weight(w), cout, ksize=1, bias=b, cfg=cfg)
+        assert U.rel_l2(U.to_nchw(y), F.conv2d(x, w, b)) < TOL, (cin, cout)
+    # two-source concat 3x3 (K tiles walk src0 then src1 inside every tap), SiLU epilogue, residual
+    N, c0, c1, cout, h, w_ = 2, 128, 64, 320, 20, 14
+    xa, xb = _rand((N, c0, h, w_), 83), _rand((N, c1, h, w_), 84)
+    wt, b = _rand((cout, c0 + c1, 3, 3), 85, 1 / math.sqrt(9 * (c0 + c1))), _rand((cout,), 86, 0.1)
+    res = _rand((N, cout, h, w_), 87)
+    ref = F.silu(F.conv2d(torch.cat([xa, xb], 1), wt, b, padding=1)) + res
+    y = U.igemm(U.nhwc16(xa), U.pack_conv_weight(wt), cout, x2=U.nhwc16(xb), bias=b, act="silu", res0=U.nhwc16(res), cfg=cfg)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+    # stride 2 (pad 1) and the folded nearest-2x upsample
+    x, wt = _rand((2, 128, 18, 12), 88), _rand((256, 128, 3, 3), 89, 1 / math.sqrt(9 * 128))
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), 256, stride=2, pad=1, cfg=cfg)
+    assert U.rel_l2(U.to_nchw(y), F.conv2d(x, wt, stride=2, padding=1)) < TOL
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), 256, ups=1, cfg=cfg)
+    assert U.rel_l2(U.to_nchw(y), F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, padding=1)) < TOL
+
+
+@pytest.mark.parametrize("cfg", [32, 33, 35])
+def test_igemm8_is_race_free_and_deterministic(cfg):
+    """race screen for the counted-vmcnt / staggered-barrier pipeline: a UNet-sized conv (many workgroups, 45 K tiles) repeated 25 times
+    must give bitwise identical outputs, and match the plain-tile kernel to fp16 rounding"""
+    N, cin, cout, h, w_ = 4, 320, 320, 32, 24
+    x, wt, b = _rand((N, cin, h, w_), 90), _rand((cout, cin, 3, 3), 91, 1 / math.sqrt(9 * cin)), _rand((cout,), 92, 0.1)
+    X, Wp = U.nhwc16(x), U.pack_conv_weight(wt)
+    first = U.igemm(X, Wp, cout, bias=b, cfg=cfg)
+    for _ in range(24):
+        assert torch.equal(U.igemm(X, Wp, cout, bias=b, cfg=cfg), first)
+    base = U.igemm(X, Wp, cout, bias=b, cfg=7)
+    assert U.rel_l2(first.float().cpu(), base.float().cpu()) < 1e-3
+    assert U.rel_l2(U.to_nchw(first), F.conv2d(x, wt, b, padding=1)) < TOL
 
 
 def test_conv3x3_stride2_pad1_and_asym():
@@ -179,7 +219,7 @@ def test_conv_small_cin_cout_and_mask_silu():
     assert U.rel_l2(U.to_nchw(y, 3), ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 6, 33])
 def test_linear_geglu(cfg):
     T, C = 200, 128
     x, w, b = _rand((1, C, T, 1), 26), _rand((8 * C, C), 27, 1 / math.sqrt(C)), _rand((8 * C,), 28, 0.1)
