@@ -26,6 +26,11 @@ enum {
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) and exp2: 4 VALU instead of the ~14 of the IEEE division above; the result is
+// rounded to fp16 by every caller
+__device__ __forceinline__ float silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 rounding of anything computed from it): one rcp, one
 // exp2 and seven FMA-class operations instead of libm erff's ~40 VALU instructions -- the GEGLU epilogues evaluate ~10^8 exact
 // (erf) GELUs per UNet forward

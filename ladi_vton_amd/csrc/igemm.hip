@@ -324,7 +324,8 @@ const CfgInfo kCfg[NCFG + 1] = {
 template <int WQ, int WP, int TQ, int TP, int BK, int NST>
 int launch_cfg(IGemmArgs a, int batch, hipStream_t st) {
     constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
-    constexpr int SMEM = NST * (BQ + BP) * BK * (int)sizeof(h16);
+    constexpr int RING = NST * (BQ + BP) * BK * (int)sizeof(h16), EPI = igemm_epilogue_lds_bytes<WQ, WP, TQ>();
+    constexpr int SMEM = RING > EPI ? RING : EPI;
     static bool attr_set = false;
     auto kfn = igemm_kernel<WQ, WP, TQ, TP, BK, NST>;
     if (!attr_set) {
@@ -407,6 +408,7 @@ size_t ladi_igemm_splitk_ws_bytes(const IGemmArgs& a, int batch) {
 
 int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st, int* stats_row_px, float* ws, size_t ws_bytes) {
     IGemmArgs a = a_in;
+    { static const int dbg = getenv("LADI_EPI_DBG") ? atoi(getenv("LADI_EPI_DBG")) : 0; a.stats_groups = dbg; }
     const int cfg_in = cfg;
     if (stats_row_px) *stats_row_px = 0;
     if (a.ksize != 1 && a.ksize != 3 && a.ksize != 4) return -1;   // 4: the stride-2 convs of the TPS matching network

@@ -2,6 +2,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "igemm_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -29,7 +30,9 @@ namespace {
 //        later than barrier 2p+1 because pieces of kt+2 are only issued from G0's load(kt+1, 0) on, interval 2(kt+1)TQ-1 >= 2p+1).
 //        region B(kt) is last read in interval 2*kt*TQ and re-staged from interval 2(kt+1)TQ-1 on.
 // ------------------------------------------------------------------------------------------------
-template <int TQ, int TP>
+// ABL: timing-only ablation switches (LADI_IGEMM8_ABL, results are wrong when set): 1 no LDS-DMA in the loop, 2 no ds_read, 4 no MFMA,
+// 8 no barriers
+template <int TQ, int TP, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IGemmArgs a) {
     constexpr int WQ = 2, WP = 4, BK = 64;
     constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
@@ -163,6 +166,16 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IGemmArgs a) {
             constexpr int q = decltype(QC)::value;
             // ---------------- load segment
             h16x8 af[4];
+            if constexpr (ABL & 2) {
+                if (q == 0 && kt == 0) {
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) bf[j][kk] = *reinterpret_cast<const h16x8*>(sX + swz<64>((wp * TP + j) * 32 + l31, kk * 2 + hh));
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { af[kk] = bf[0][kk]; asm volatile("" : "+v"(af[kk])); }
+            } else {
             if constexpr (q == 0) {
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
@@ -173,37 +186,66 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IGemmArgs a) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
                 af[kk] = *reinterpret_cast<const h16x8*>(sW + swz<64>(q * 64 + wq * 32 + l31, kk * 2 + hh));
+            }
+            if constexpr (!(ABL & 1))
             static_for<q * PPP, ((q + 1) * PPP < NPIECE ? (q + 1) * PPP : NPIECE)>([&](auto IC) { issue_piece(IC, nxt); });
             // pieces this wave has issued AFTER the last piece that phase q+1 reads (in-order completion): see the header comment
             constexpr int issued_next = ((q + 1) * PPP < NPIECE ? (q + 1) * PPP : NPIECE);
             constexpr int N = (q + 1 < TQ) ? (NPIECE - 1 - (NB + q + 1)) + issued_next : (NA - 1);
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+            if constexpr (ABL & 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
             // ---------------- MFMA segment
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+            if constexpr (ABL & 4) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(af[kk]), "v"(bf[0][kk]), "v"(bf[TP - 1][kk]));
+            } else {
+            if constexpr (ABL & 32) {      // timing only: 8 independent accumulators per phase (no accumulate chain)
+                static_for<0, 4>([&](auto KC) {
+                    constexpr int kk = decltype(KC)::value;
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+                        acc[(q + kk) % TQ][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[j][kk], acc[(q + kk) % TQ][j], 0, 0, 0);
+                });
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
                     acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[j][kk], acc[q][j], 0, 0, 0);
+            }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_barrier" ::: "memory");
+            if constexpr (!(ABL & 8)) asm volatile("s_barrier" ::: "memory");
         });
         advance_stage(kt + 2);
     }
     if (wq == 0) asm volatile("s_barrier" ::: "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tail pieces (zeros) must not land in the epilogue's patches
 
+    if constexpr (ABL & 16) {      // no epilogue: keep the accumulators alive, store nothing
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TQ; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 12345.678f) reinterpret_cast<h16*>(a.out)[0] = (h16)s;
+        return;
+    }
     igemm_epilogue<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane);
 }
 
-template <int TQ, int TP>
+template <int TQ, int TP, int ABL = 0>
 int launch_cfg8(IGemmArgs a, int batch, hipStream_t st) {
     constexpr int BQ = 64 * TQ, BP = 128 * TP;
     constexpr int SMEM = 2 * (BQ + BP) * 64 * (int)sizeof(h16);
+    static_assert(SMEM >= igemm_epilogue_lds_bytes<2, 4, TQ>(), "epilogue patches must fit in the staging buffers");
     static bool attr_set = false;
-    auto kfn = igemm8_kernel<TQ, TP>;
+    auto kfn = igemm8_kernel<TQ, TP, ABL>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
             return -10;
@@ -224,6 +266,16 @@ int launch_cfg8(IGemmArgs a, int batch, hipStream_t st) {
 }  // namespace
 
 int ladi_launch_igemm8(const IGemmArgs& a, int tq, int tp, int batch, hipStream_t st) {
+    static const int abl = getenv("LADI_IGEMM8_ABL") ? atoi(getenv("LADI_IGEMM8_ABL")) : 0;
+    if (abl && tq == 5 && tp == 2) {
+        switch (abl) {
+            case 1: return launch_cfg8<5, 2, 1>(a, batch, st);       // no LDS-DMA in the loop
+            case 4: return launch_cfg8<5, 2, 4>(a, batch, st);       // no MFMA
+            case 16: return launch_cfg8<5, 2, 16>(a, batch, st);     // no epilogue
+            case 27: return launch_cfg8<5, 2, 27>(a, batch, st);     // MFMA only (no DMA / ds_read / barriers / epilogue)
+            default: break;
+        }
+    }
     if (tq == 5 && tp == 2) return launch_cfg8<5, 2>(a, batch, st);
     if (tq == 4 && tp == 2) return launch_cfg8<4, 2>(a, batch, st);
     return -7;

@@ -6,6 +6,10 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// LDS bytes the fused epilogue uses: one transpose patch per wave + the per-W-row additive vector
+template <int WQ, int WP, int TQ>
+constexpr int igemm_epilogue_lds_bytes() { return WQ * WP * 32 * (TQ * 32 + 4) * 2 + WQ * TQ * 32 * 4; }
+
 template <int BK>
 __device__ __forceinline__ int swz(int row, int chunk) {
     if constexpr (BK == 64) return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
@@ -13,13 +17,15 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Epilogue shared by the kernels of this file.  On entry every wave holds acc[TQ][TP] (32x32 MFMA accumulators) of its
+// Epilogue shared by the implicit-GEMM kernels.  On entry every wave holds acc[TQ][TP] (32x32 MFMA accumulators) of its
 // (TQ*32 channels) x (TP*32 pixels) sub-tile at channel offset q0 + wq*TQ*32, pixel offset p0 + wp*TP*32; the staging ring is dead
-// (the caller has drained every LDS-DMA).
+// (the caller has drained every LDS-DMA).  igemm_epilogue() dispatches to
+//   * igemm_epilogue_fast     fp16 output with 16-byte aligned rows (every layer of the UNet / VAE / EMASC except conv_out),
+//   * igemm_epilogue_generic  everything else (fp32 output, narrow / unaligned outputs): element-wise bounds checks.
 // ------------------------------------------------------------------------------------------------
 template <int WQ, int WP, int TQ, int TP>
-__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& a, f32x16 (&acc)[TQ][TP], h16* smem, const int q0, const int p0,
-                                               const int pt, const int z, const int wave, const int lane) {
+__device__ __forceinline__ void igemm_epilogue_generic(const IGemmArgs& a, f32x16 (&acc)[TQ][TP], h16* smem, const int q0, const int p0,
+                                                       const int pt, const int z, const int wave, const int lane) {
     const int wq = wave / WP, wp = wave % WP;
     const int l31 = lane & 31, hh = lane >> 5;
     // ------------------------------------------------------------------------------------------
@@ -205,5 +211,208 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& a, f32x16 (&acc)
     }
 }
 
+
+
+// Fast path.  Three things bound an epilogue on this chip and shape it:
+//   * VMEM counters are in-order and count stores too: a load issued after stores cannot be waited for without draining those stores
+//     (~1 us each).  So the global LOADS of a pixel sub-tile (the residual rows) are all issued before its first STORE, and the
+//     per-channel vectors (bias, time-embedding row) never come from global memory inside the loops: they are summed once per
+//     workgroup into an LDS vector;
+//   * lanes own pixel COLUMNS after the K loop, NHWC rows want lanes along channels: each wave transposes its 32-pixel sub-tiles
+//     through a private LDS patch so that every global access is a 16-byte piece of a contiguous run of one pixel row;
+//   * all trip counts are compile-time (GEGLU is a template flag), so the passes of a sub-tile are unrolled and their LDS reads, loads
+//     and stores overlap.
+template <int WQ, int WP, int TQ, int TP, bool GEGLU>
+__device__ __forceinline__ void igemm_epilogue_fast(const IGemmArgs& a, f32x16 (&acc)[TQ][TP], h16* smem, const int q0, const int p0,
+                                                    const int pt, const int z, const int wave, const int lane) {
+    static_assert(!GEGLU || (TQ % 2 == 0), "GEGLU pairs 32-row blocks (u | g)");
+    constexpr int NW = WQ * WP, NT = 64 * NW, BQ = WQ * TQ * 32;
+    constexpr int CWF = TQ * 32;                    // W rows of this wave
+    constexpr int RSF = CWF + 4;                    // padded patch row stride (halves): 8-byte aligned, conflict-free b64 writes
+    constexpr int CW = GEGLU ? CWF / 2 : CWF;       // output channels of this wave
+    constexpr int LPR = CW / 8;                     // lanes per pixel row in the read-back (8 channels = 16 B each)
+    constexpr int RPW = 64 / LPR;                   // pixel rows per read-back pass
+    constexpr int NPASS = (32 + RPW - 1) / RPW;
+    const int wq = wave / WP, wp = wave % WP;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int Qout = GEGLU ? a.Q / 2 : a.Q;
+    const size_t zo = (size_t)z * a.bs_out;
+    const size_t zr = (size_t)z * a.bs_res;
+
+    __syncthreads();                                // every wave is done with the staging ring
+    h16* patch = smem + wave * (32 * RSF);
+    float* cadd = reinterpret_cast<float*>(smem + NW * (32 * RSF));      // [BQ] per-W-row additive vector: bias (+ time-embedding row)
+    {
+        const float* rowadd = a.rowadd;
+        if (rowadd && a.rowadd_idx) rowadd += (size_t)(*a.rowadd_idx) * a.rowadd_stride;
+        for (int c = threadIdx.x; c < BQ; c += NT) {
+            const int q = q0 + c;
+            float v = 0.f;
+            if (q < a.Q) {
+                if (a.bias && !a.bias_per_pixel) v = (float)a.bias[q];
+                if (!GEGLU && rowadd) v += rowadd[q];
+            }
+            cadd[c] = v;
+        }
+    }
+    __syncthreads();
+
+    const int rb_row = lane / LPR, rb_chunk = lane - rb_row * LPR;
+    const bool rb_lane = rb_row < RPW;
+    const int cw0 = GEGLU ? (q0 + wq * CWF) / 2 : (q0 + wq * CWF);       // first output channel of this wave
+    const int co8 = cw0 + rb_chunk * 8;
+    const bool cok = rb_lane && co8 < Qout;
+    const bool want_stats = (a.stats != nullptr);
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+
+    static_for<0, TP>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        const int pbase = p0 + (wp * TP + j) * 32;
+        // (1) lane = pixel column: per-channel vector / activation, round to fp16, 8-byte LDS writes
+        const int pcol = pbase + l31;
+        const float pb = (a.bias && a.bias_per_pixel && pcol < a.P) ? (float)a.bias[pcol] : 0.f;
+        // the activation is selected ONCE per sub-tile (wave-uniform switch around the unrolled loops): a per-element `if (act == ...)`
+        // chain costs ~20 scalar branches per 4 values, more than all the arithmetic of this epilogue together
+        auto step1 = [&](auto ActC) {
+            constexpr int ACT = decltype(ActC)::value;
+            static_for<0, TQ>([&](auto Ic) {
+                constexpr int iu = decltype(Ic)::value;
+                if constexpr (!(GEGLU && (iu & 1))) {   // GEGLU: 32-row blocks alternate u | g; g is consumed with its u block
+                    const int wr0 = (wq * TQ + iu) * 32 + 4 * hh;                        // W row (inside the workgroup tile) of reg 0
+                    const int lc0 = (GEGLU ? (iu / 2) * 32 : iu * 32) + 4 * hh;          // channel inside the wave patch
+                    f32x4 ca[4], cg[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        ca[g] = *reinterpret_cast<const f32x4*>(cadd + wr0 + 8 * g);
+                        if constexpr (GEGLU) cg[g] = *reinterpret_cast<const f32x4*>(cadd + wr0 + 8 * g + 32);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        h16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = acc[iu][j][4 * g + e] + ca[g][e] + pb;
+                            if constexpr (GEGLU) {
+                                constexpr int ig = (iu + 1 < TQ) ? iu + 1 : iu;
+                                x *= gelu_f(acc[ig][j][4 * g + e] + cg[g][e]);
+                            } else if constexpr (ACT == LADI_ACT_SILU) x = silu_fast(x);
+                            else if constexpr (ACT == LADI_ACT_GELU) x = gelu_f(x);
+                            else if constexpr (ACT == LADI_ACT_RELU) x = fmaxf(x, 0.f);
+                            o[e] = (h16)(x * a.out_scale);
+                        }
+                        *reinterpret_cast<h16x4*>(patch + l31 * RSF + lc0 + 8 * g) = o;
+                    }
+                }
+            });
+        };
+        if (!(a.stats_groups & 2)) {
+            if constexpr (GEGLU) step1(IntC<LADI_ACT_GEGLU>{});
+            else if (a.act == LADI_ACT_SILU) step1(IntC<LADI_ACT_SILU>{});
+            else if (a.act == LADI_ACT_GELU) step1(IntC<LADI_ACT_GELU>{});
+            else if (a.act == LADI_ACT_RELU) step1(IntC<LADI_ACT_RELU>{});
+            else step1(IntC<LADI_ACT_NONE>{});
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");      // keep the loads below behind the patch write: the accumulators of this sub-tile are dead now
+        // the read-back passes run in groups of at most GP: (1b) every global load of a group (residual rows, in read-back layout)
+        // before the group's first store, (2) lane = (pixel row, 8-channel chunk): residuals, mask, statistics, 16-byte coalesced stores
+        constexpr int GP = NPASS > 6 ? (NPASS + 1) / 2 : NPASS;
+        static_for<0, (NPASS + GP - 1) / GP>([&](auto Gc) {
+        constexpr int i0 = decltype(Gc)::value * GP;
+        constexpr int i1 = (i0 + GP < NPASS) ? i0 + GP : NPASS;
+        h16x8 r0v[GP], r1v[GP];
+        bool pok[GP];
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const int prw = i * RPW + rb_row;
+            const int p = pbase + prw;
+            pok[i - i0] = cok && prw < 32 && p < a.P;
+            if (a.res0 && pok[i - i0]) r0v[i - i0] = *reinterpret_cast<const h16x8*>(a.res0 + zr + (size_t)p * a.ldr0 + co8);
+            if (a.res1 && pok[i - i0]) r1v[i - i0] = *reinterpret_cast<const h16x8*>(a.res1 + zr + (size_t)p * a.ldr1 + co8);
+        }
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const int prw = i * RPW + rb_row;
+            const int p = pbase + prw;
+            if (pok[i - i0]) {
+                const h16* src = patch + prw * RSF + rb_chunk * 8;
+                const h16x4 lo = *reinterpret_cast<const h16x4*>(src);
+                const h16x4 hi = *reinterpret_cast<const h16x4*>(src + 4);
+                h16x8 o;
+                if (a.res0 || a.res1 || a.mask) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = (float)lo[e]; v[4 + e] = (float)hi[e]; }
+                    if (a.res0) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)r0v[i - i0][e]; }
+                    if (a.res1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)r1v[i - i0][e]; }
+                    if (a.mask) {
+                        const float mk = 1.f - (float)a.mask[p];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= mk;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (h16)v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+                }
+                if (!(a.stats_groups & 1)) *reinterpret_cast<h16x8*>(reinterpret_cast<h16*>(a.out) + zo + (size_t)p * a.ldo + co8) = o;
+                else if (o[0] == (h16)12345.f) *reinterpret_cast<h16x8*>(reinterpret_cast<h16*>(a.out)) = o;
+                if (want_stats) {   // statistics of the values as stored (fp16-rounded)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float q = (float)o[e]; ssum[e] += q; ssq[e] += q * q; }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        });
+        __builtin_amdgcn_wave_barrier();
+    });
+
+    // optional per-channel statistics of the OUTPUT (sum, sum of squares over this wave's TP*32 pixels) for the GroupNorm that
+    // consumes it: plain stores of partial rows, no atomics (deterministic); the launcher guarantees sample alignment
+    if (want_stats) {
+#pragma unroll
+        for (int k = 1; k < RPW; ++k) {
+            const int srcl = lane + k * LPR;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float s1 = __shfl(ssum[e], srcl), s2 = __shfl(ssq[e], srcl);
+                if (lane < LPR) { ssum[e] += s1; ssq[e] += s2; }
+            }
+        }
+        if (lane < LPR && co8 < Qout) {
+            const size_t row = (size_t)pt * WP + wp;
+            float* sp = a.stats + (row * Qout + co8) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<float4*>(sp + 4 * e) = make_float4(ssum[2 * e], ssq[2 * e], ssum[2 * e + 1], ssq[2 * e + 1]);
+        }
+    }
+}
+
+template <int WQ, int WP, int TQ, int TP>
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& a, f32x16 (&acc)[TQ][TP], h16* smem, const int q0, const int p0,
+                                               const int pt, const int z, const int wave, const int lane) {
+    const bool geglu = (a.act == LADI_ACT_GEGLU);
+    const int Qout = geglu ? a.Q / 2 : a.Q;
+    // workgroup-uniform: fp16 rows whose 8-channel chunks are whole and 16-byte aligned (ld % 8 == 0 with 16-byte aligned bases)
+    const bool fast = !a.out_f32 && !(a.ldo & 7) && !(Qout & 7) && (!a.res0 || !(a.ldr0 & 7)) && (!a.res1 || !(a.ldr1 & 7)) &&
+                      !((reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.res0) | reinterpret_cast<uintptr_t>(a.res1)) & 15) &&
+                      !(((size_t)z * a.bs_out | (size_t)z * a.bs_res) & 7) && (!a.stats || !(reinterpret_cast<uintptr_t>(a.stats) & 15));
+    if (fast) {
+        if constexpr (TQ % 2 == 0) {
+            if (geglu) { igemm_epilogue_fast<WQ, WP, TQ, TP, true>(a, acc, smem, q0, p0, pt, z, wave, lane); return; }
+        }
+        if (!geglu) { igemm_epilogue_fast<WQ, WP, TQ, TP, false>(a, acc, smem, q0, p0, pt, z, wave, lane); return; }
+    }
+    igemm_epilogue_generic<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane);
+}
 
 }  // namespace

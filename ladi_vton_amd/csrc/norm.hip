@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ s
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float y = (float)v[e] * sc[e] + sh[e];
-                if (silu) y = silu_f(y);
+                if (silu) y = silu_fast(y);
                 if (add) y += (float)ad[e];
                 o[e] = (h16)y;
             }

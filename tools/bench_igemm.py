@@ -16,6 +16,11 @@ import ctypes  # noqa: E402
 # (name, H, W, Cin, Cout, ksize, per-sample scaling: True = multiply batch by n)
 SHAPES = [
     ("unet conv3 320->320 @64x48", 64, 48, 320, 320, 3),
+    ("ovh lin 64->320 T3072", 3072, 1, 64, 320, 1),
+    ("ovh lin 128->320 T3072", 3072, 1, 128, 320, 1),
+    ("ovh lin 256->320 T3072", 3072, 1, 256, 320, 1),
+    ("ovh lin 512->320 T3072", 3072, 1, 512, 320, 1),
+    ("ovh conv3 64->320 @64x48", 64, 48, 64, 320, 3),
     ("unet conv3 640->640 @32x24", 32, 24, 640, 640, 3),
     ("unet conv3 1280->1280 @16x12", 16, 12, 1280, 1280, 3),
     ("unet conv3 1280->1280 @8x6", 8, 6, 1280, 1280, 3),
