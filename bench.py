@@ -230,8 +230,8 @@ def main():
         lib.ladi_profile_igemm_enable(1)
         unet.time_forward(n, h, w, a.roofline_iters)   # 1 warm-up + roofline_iters timed forwards, all recorded
         lib.ladi_profile_igemm_enable(0)
-        prof = (ctypes.c_double * 128)()
-        lib.ladi_profile_igemm_collect(prof, 128)
+        prof = (ctypes.c_double * 192)()
+        lib.ladi_profile_igemm_collect(prof, 192)
         names = {1: "igemm_kernel<2,2,2,4,32,3> (Q128xP256)", 2: "igemm_kernel<2,2,5,2,32,2> (Q320xP128)", 3: "igemm_kernel<2,2,2,2,32,3> (Q128xP128)",
                  4: "igemm_kernel<2,2,2,1,32,3> (Q128xP64)", 5: "igemm_kernel<2,2,1,1,32,3> (Q64xP64)", 6: "igemm_kernel<2,2,4,2,32,3> (Q256xP128)"}
         per = {}
@@ -247,7 +247,10 @@ def main():
                       27: "linear_xs_kernel (32 px/wave, 5 channel slices)"})
         names.update({28: "igemm_kernel<4,2,2,2,32,3> + split-K 4", 29: "igemm_kernel<4,2,2,2,32,3> + split-K 8",
                       30: "igemm_kernel<2,4,2,2,32,3> + split-K 4", 31: "igemm_kernel<2,4,2,2,32,3> + split-K 8"})
-        for c_ in range(1, 32):
+        names.update({32: "igemm8_kernel<5,2> (Q320xP256, phase-staggered)", 33: "igemm8_kernel<4,2> (Q256xP256, phase-staggered)",
+                      34: "igemm8_kernel<5,2> + split-K 2", 35: "igemm8_kernel<5,2> + split-K 4", 36: "igemm8_kernel<4,2> + split-K 2",
+                      37: "igemm8_kernel<4,2> + split-K 4", 38: "igemm8_kernel<4,2> + split-K 8"})
+        for c_ in range(1, 39):
             ms, fl, cnt = prof[c_ * 3], prof[c_ * 3 + 1], prof[c_ * 3 + 2]
             if cnt > 0:
                 per[c_] = dict(kernel=names[c_], launches=int(cnt), avg_ms=ms / cnt, flop_per_launch=fl / cnt, tflops=fl / ms / 1e9)

@@ -408,7 +408,6 @@ size_t ladi_igemm_splitk_ws_bytes(const IGemmArgs& a, int batch) {
 
 int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st, int* stats_row_px, float* ws, size_t ws_bytes) {
     IGemmArgs a = a_in;
-    { static const int dbg = getenv("LADI_EPI_DBG") ? atoi(getenv("LADI_EPI_DBG")) : 0; a.stats_groups = dbg; }
     const int cfg_in = cfg;
     if (stats_row_px) *stats_row_px = 0;
     if (a.ksize != 1 && a.ksize != 3 && a.ksize != 4) return -1;   // 4: the stride-2 convs of the TPS matching network

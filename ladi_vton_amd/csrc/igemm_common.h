@@ -307,13 +307,11 @@ __device__ __forceinline__ void igemm_epilogue_fast(const IGemmArgs& a, f32x16 (
                 }
             });
         };
-        if (!(a.stats_groups & 2)) {
-            if constexpr (GEGLU) step1(IntC<LADI_ACT_GEGLU>{});
-            else if (a.act == LADI_ACT_SILU) step1(IntC<LADI_ACT_SILU>{});
-            else if (a.act == LADI_ACT_GELU) step1(IntC<LADI_ACT_GELU>{});
-            else if (a.act == LADI_ACT_RELU) step1(IntC<LADI_ACT_RELU>{});
-            else step1(IntC<LADI_ACT_NONE>{});
-        }
+        if constexpr (GEGLU) step1(IntC<LADI_ACT_GEGLU>{});
+        else if (a.act == LADI_ACT_SILU) step1(IntC<LADI_ACT_SILU>{});
+        else if (a.act == LADI_ACT_GELU) step1(IntC<LADI_ACT_GELU>{});
+        else if (a.act == LADI_ACT_RELU) step1(IntC<LADI_ACT_RELU>{});
+        else step1(IntC<LADI_ACT_NONE>{});
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");      // keep the loads below behind the patch write: the accumulators of this sub-tile are dead now
         // the read-back passes run in groups of at most GP: (1b) every global load of a group (residual rows, in read-back layout)
@@ -362,8 +360,7 @@ __device__ __forceinline__ void igemm_epilogue_fast(const IGemmArgs& a, f32x16 (
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
                 }
-                if (!(a.stats_groups & 1)) *reinterpret_cast<h16x8*>(reinterpret_cast<h16*>(a.out) + zo + (size_t)p * a.ldo + co8) = o;
-                else if (o[0] == (h16)12345.f) *reinterpret_cast<h16x8*>(reinterpret_cast<h16*>(a.out)) = o;
+                *reinterpret_cast<h16x8*>(reinterpret_cast<h16*>(a.out) + zo + (size_t)p * a.ldo + co8) = o;
                 if (want_stats) {   // statistics of the values as stored (fp16-rounded)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float q = (float)o[e]; ssum[e] += q; ssq[e] += q * q; }
