@@ -1,10 +1,17 @@
 #!/usr/bin/env python
 """bench.py — try-on images/s of the native LaDI-VTON hot path (BASELINE.json metric).
 
-One "step" = one full pass of the hot path over one batch: B try-on pairs in (device resident) -> VAE encodes + EMASC ->
-50 scheduler steps of the CFG UNet -> VAE decode with EMASC skips -> uint8 images (all-gathered over ranks when N > 1).
-Workload = BASELINE.json configs[1]: batch 8 per GPU, 50 steps, 512x384, fp16 storage / fp32 accumulate, synthetic inputs and a
-deterministic random-init checkpoint of the released architecture (no weights or datasets are reachable offline).
+One "step" = one full pass of the hot path over one batch: B try-on pairs in (device resident) -> [producers, configs 2/3 only: CLIP
+vision encoder -> inversion adapter -> CLIP text encoder with the pseudo-word splice] -> VAE encodes + EMASC -> N scheduler steps of
+the CFG UNet (hipGraph) -> VAE decode with EMASC skips -> uint8 images (all-gathered over ranks when N_gpus > 1).
+
+  --config 1 (default)  BASELINE.json configs[1]: batch 8 / GPU, 50 PNDM steps, 512x384            <- the configuration `metric` is quoted on
+  --config 2            configs[2]: batch 32, 50 PNDM, 512x384, inversion adapter + vision / text encoders + EMASC inside the step
+  --config 3            configs[3]: batch 256 over 8 GPUs = 32 / GPU (run with --gpus 8), producers on
+  --config 4            configs[4]: 1024x768, 100 DDIM steps, batch 8 / GPU (64 over 8 GPUs)
+Synthetic inputs with the datasets' shapes / value ranges and a deterministic random-init checkpoint of the released architecture
+(no weights or datasets are reachable offline).  Global-batch row g depends only on g (per-row generators), rows are sharded
+contiguously over ranks (ladi_vton_amd.parallel.run_sharded), so results do not depend on the world size.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -14,7 +21,11 @@ import argparse
 import ctypes
 import json
 import os
+import re
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -26,8 +37,30 @@ if ROOT not in sys.path:
 
 # algorithmic work (SURVEY.md §8d / BASELINE.md §2), 2*MAC FLOPs
 UNET_FLOP_PER_SAMPLE_64x48 = 581.70e9
-TRYON_FLOP_PER_IMAGE = {"ddim": 62.16e12, "pndm": 63.32e12}
+TRYON_FLOP_PER_IMAGE = {("ddim", 50, 512): 62.16e12, ("pndm", 50, 512): 63.32e12, ("ddim", 100, 1024): 644.9e12}
 PEAK_F16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+CONFIGS = {   # BASELINE.json `configs` index -> (batch per GPU, steps, scheduler, H, W, producers)
+    1: dict(batch=8, steps=50, scheduler="pndm", H=512, W=384, producers=False,
+            name="BASELINE configs[1]: VITON-HD-paired-like, batch 8 per GPU"),
+    2: dict(batch=32, steps=50, scheduler="pndm", H=512, W=384, producers=True,
+            name="BASELINE configs[2]: DressCode-upper_body-unpaired-like, batch 32, inversion adapter + CLIP vision / text encoders in the step"),
+    3: dict(batch=32, steps=50, scheduler="pndm", H=512, W=384, producers=True,
+            name="BASELINE configs[3]: VITON-HD-unpaired-like, batch 256 over 8 GPUs = 32 per GPU"),
+    4: dict(batch=8, steps=100, scheduler="ddim", H=1024, W=768, producers=False,
+            name="BASELINE configs[4]: DressCode-like 1024x768, batch 64 over 8 GPUs = 8 per GPU"),
+}
+# tile configuration id (csrc/igemm.hip kCfg) -> kernel symbol as rocprofv3 prints it; split-K variants launch the same symbol
+SYMBOL = {1: "igemm_kernel<2, 2, 2, 4, 32, 3>", 2: "igemm_kernel<2, 2, 5, 2, 32, 2>", 3: "igemm_kernel<2, 2, 2, 2, 32, 3>",
+          4: "igemm_kernel<2, 2, 2, 1, 32, 3>", 5: "igemm_kernel<2, 2, 1, 1, 32, 3>", 6: "igemm_kernel<2, 2, 4, 2, 32, 3>",
+          7: "igemm_kernel<2, 2, 2, 2, 64, 2>", 8: "igemm_kernel<2, 2, 2, 4, 64, 2>", 9: "igemm_kernel<2, 2, 2, 1, 64, 3>",
+          10: "igemm_kernel<2, 2, 5, 2, 64, 2>", 16: "igemm_kernel<2, 2, 1, 1, 32, 4>", 17: "igemm_kernel<2, 2, 2, 1, 32, 4>",
+          18: "igemm_kernel<2, 2, 2, 2, 32, 4>", 19: "igemm_kernel<2, 4, 2, 2, 32, 3>", 20: "igemm_kernel<4, 2, 2, 2, 32, 3>",
+          21: "igemm_kernel<2, 4, 4, 2, 32, 3>", 22: "igemm_kernel<2, 4, 5, 2, 64, 2>", 32: "igemm8_kernel<5, 2, 0>",
+          33: "igemm8_kernel<4, 2, 0>"}
+SYMBOL.update({11: SYMBOL[9], 12: SYMBOL[9], 13: SYMBOL[9], 14: SYMBOL[7], 15: SYMBOL[7], 28: SYMBOL[20], 29: SYMBOL[20], 30: SYMBOL[19],
+               31: SYMBOL[19], 34: SYMBOL[32], 35: SYMBOL[32], 36: SYMBOL[33], 37: SYMBOL[33], 38: SYMBOL[33]})
+SYMBOL.update({c: "linear_xs_kernel" for c in range(23, 28)})
+NCFG = 38
 
 
 def parse():
@@ -35,15 +68,20 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--batch", type=int, default=8, help="try-on pairs per GPU (weak scaling)")
-    p.add_argument("--inference-steps", type=int, default=50)
-    p.add_argument("--scheduler", default="pndm", choices=["pndm", "ddim"])
-    p.add_argument("--height", type=int, default=512)
-    p.add_argument("--width", type=int, default=384)
+    p.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[] index")
+    p.add_argument("--batch", type=int, default=None, help="override: try-on pairs per GPU (weak scaling)")
+    p.add_argument("--inference-steps", type=int, default=None)
+    p.add_argument("--scheduler", default=None, choices=["pndm", "ddim"])
+    p.add_argument("--height", type=int, default=None)
+    p.add_argument("--width", type=int, default=None)
     p.add_argument("--size", default="full", choices=["full", "tiny"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-runs", type=int, default=1, help="end-to-end runs of config #0 on the host cores (median reported; BASELINE.md §3 protocol: 3)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--measure-traffic", action="store_true",
+                   help="collect FETCH_SIZE / WRITE_SIZE of the dominant kernel NOW (two rocprofv3 --pmc child runs of --roofline-only) "
+                        "instead of reading the committed, digest-checked profiles/")
     p.add_argument("--roofline-only", action="store_true",
                    help="only the dominant-kernel measurement: CFG UNet forwards at the bench batch (the command the rocprofv3 "
                         "summaries under profiles/ are taken from)")
@@ -51,70 +89,125 @@ def parse():
     return p.parse_args()
 
 
-def synthetic_device_inputs(B, H, W, L, D, device, seed):
-    """synthetic inputs with the datasets' shapes and value ranges, generated per rank on the device"""
-    g = torch.Generator(device="cpu").manual_seed(seed)
+# ---------------------------------------------------------------------------------------------------------------------------------
+# synthetic global batch: row g is a function of g only
+# ---------------------------------------------------------------------------------------------------------------------------------
+def make_rows(lo, hi, H, W, L, D, device, seed=1234):
+    """rows [lo, hi) of the global batch (SURVEY.md §8d shapes and value ranges); the shared negative prompt is row-independent"""
     F = torch.nn.functional
+    ys = torch.arange(H, dtype=torch.float32)[None, :, None]
+    xs = torch.arange(W, dtype=torch.float32)[None, None, :]
+    rows = {k: [] for k in ("image", "mask_image", "pose_map", "warped_cloth", "cloth", "prompt_embeds", "noise_cloth", "noise_latents",
+                            "noise_masked", "word_ids")}
+    for gidx in range(lo, hi):
+        g = torch.Generator(device="cpu").manual_seed(seed * 1000003 + gidx)
 
-    def smooth():
-        low = torch.rand((B, 3, H // 8, W // 8), generator=g) * 2 - 1
-        return F.interpolate(low, size=(H, W), mode="bilinear", align_corners=False).clamp(-1, 1)
+        def smooth():
+            low = torch.rand((1, 3, H // 8, W // 8), generator=g) * 2 - 1
+            return F.interpolate(low, size=(H, W), mode="bilinear", align_corners=False).clamp(-1, 1)[0]
 
-    image, cloth = smooth(), smooth()
-    mask = torch.zeros(B, 1, H, W)
-    mask[:, :, H // 4:3 * H // 4, W // 4:3 * W // 4] = 1.0
-    ys = torch.arange(H, dtype=torch.float32)[None, None, :, None]
-    xs = torch.arange(W, dtype=torch.float32)[None, None, None, :]
-    cy = torch.rand((B, 18, 1, 1), generator=g) * H
-    cx = torch.rand((B, 18, 1, 1), generator=g) * W
-    pose = torch.exp(-((ys - cy) ** 2 + (xs - cx) ** 2) / 81.0)
-    pose[:, 7::9] = 0.0
-    h, w = H // 8, W // 8
-    d = dict(image=image, mask_image=mask, pose_map=pose, warped_cloth=cloth,
-             prompt_embeds=torch.randn((B, L, D), generator=g), negative_prompt_embeds=torch.randn((1, L, D), generator=g).expand(B, L, D).contiguous(),
-             noise_cloth=torch.randn((B, 4, h, w), generator=g), noise_latents=torch.randn((B, 4, h, w), generator=g),
-             noise_masked=torch.randn((B, 4, h, w), generator=g))
+        rows["image"].append(smooth()); rows["warped_cloth"].append(smooth()); rows["cloth"].append(smooth())
+        m = torch.zeros(1, H, W); m[:, H // 4:3 * H // 4, W // 4:3 * W // 4] = 1.0
+        rows["mask_image"].append(m)
+        cy = torch.rand((18, 1, 1), generator=g) * H
+        cx = torch.rand((18, 1, 1), generator=g) * W
+        pose = torch.exp(-((ys - cy) ** 2 + (xs - cx) ** 2) / 81.0)
+        pose[7::9] = 0.0
+        rows["pose_map"].append(pose)
+        rows["prompt_embeds"].append(torch.randn((L, D), generator=g))
+        for k in ("noise_cloth", "noise_latents", "noise_masked"):
+            rows[k].append(torch.randn((4, H // 8, W // 8), generator=g))
+        # "a photo of a model wearing <category garment> $ x16" (src/inference.py:289): BOS, 8-10 words, 16 pseudo-word slots, EOS, padding
+        ids = torch.zeros(77, dtype=torch.int32)
+        nw = 8 + gidx % 3
+        ids[0] = 49406
+        ids[1:1 + nw] = torch.randint(300, 40000, (nw,), generator=g).int()
+        ids[1 + nw:1 + nw + 16] = 259
+        ids[1 + nw + 16] = 49407
+        rows["word_ids"].append(ids)
     out = {}
-    for k, v in d.items():
+    for k, v in rows.items():
+        t = torch.stack(v)
         if k.startswith("noise"):
-            out[k] = v.to(device)
+            out[k] = t.to(device)
+        elif k == "word_ids":
+            out[k] = t
         else:
-            out[k] = v.to(device=device, dtype=torch.float16)
+            out[k] = t.to(device=device, dtype=torch.float16)
+    gneg = torch.Generator(device="cpu").manual_seed(seed + 4)
+    out["negative_prompt_embeds"] = torch.randn((1, L, D), generator=gneg).expand(hi - lo, L, D).contiguous().to(device=device, dtype=torch.float16)
     return out
 
 
-def pmc_traffic(kernel_label):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_*.txt: separate
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM). None if absent."""
-    import re
-    m = re.match(r"igemm_kernel<([0-9,]+)>", kernel_label)
-    if m:
-        pat = "igemm_kernel<" + ", ".join(m.group(1).split(",")) + ">"
-    elif kernel_label.startswith("linear_xs_kernel"):
-        pat = "linear_xs_kernel"     # first (= most time-consuming) instantiation listed in the PMC summary
-    else:
+# ---------------------------------------------------------------------------------------------------------------------------------
+# roofline.traffic: HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes
+# ---------------------------------------------------------------------------------------------------------------------------------
+def lib_digest():
+    try:
+        return open(os.path.join(ROOT, "ladi_vton_amd", "csrc", "_obj", "stamp")).read().strip()
+    except OSError:
         return None
+
+
+def _pmc_avg_kib(db_path, symbol):
+    import sqlite3
+    c = sqlite3.connect(db_path)
+    rows = c.execute("select name, count(*), avg(counter_value) from pmc_events group by name").fetchall()
+    for n, cnt, avg in rows:
+        if symbol in re.sub(r"\(anonymous namespace\)::", "", n):
+            return float(avg), int(cnt)
+    return None, 0
+
+
+def traffic_measured(symbol, extra_args):
+    """two separate rocprofv3 --pmc child runs of `bench.py --roofline-only` (FETCH_SIZE and WRITE_SIZE cannot share a pass:
+    MI355X_MICROARCH.md §rocprofv3 PMC slots); FETCH_SIZE doubled (gfx950 reports 64 B per 128-B request, §HBM)"""
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ladi_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"), "--roofline-only",
+               "--no-cpu-baseline"] + extra_args
+        env = dict(os.environ, TMPDIR="/tmp")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+        dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+        if r.returncode != 0 or not dbs:
+            return None, "rocprofv3 --pmc %s failed (rc %d)" % (ctr, r.returncode)
+        avg, cnt = _pmc_avg_kib(dbs[0], symbol)
+        if avg is None:
+            return None, "kernel %s not in the %s pass" % (symbol, ctr)
+        vals[ctr] = (avg * 1024.0, cnt)
+        subprocess.run(["rm", "-rf", d])
+    f, w = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    return {"bytes_per_launch": round(2.0 * f + w), "fetch_bytes_x2": round(2.0 * f), "write_bytes": round(w),
+            "launches": vals["FETCH_SIZE"][1], "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled)"}, None
+
+
+def traffic_committed(symbol):
+    """profiles/r02_pmc_{fetch,write}_size.txt, valid only for the library build they were taken with (first line: # lib_digest=...)"""
     vals = {}
     for tag in ("fetch", "write"):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_%s_size.txt" % tag)
+        path = os.path.join(ROOT, "profiles", "r02_pmc_%s_size.txt" % tag)
         if not os.path.exists(path):
-            return None
-        for line in open(path):
-            if pat in line:
-                f = line.split()
-                vals[tag] = float(f[-2]) * 1024.0   # avg KiB per dispatch -> bytes
+            return None, "no committed PMC pass (profiles/r02_pmc_%s_size.txt)" % tag
+        lines = open(path).read().splitlines()
+        m = re.match(r"# lib_digest=(\w+)", lines[0]) if lines else None
+        if not m or m.group(1) != lib_digest():
+            return None, "committed PMC passes are stale (taken with another library build); re-run with --measure-traffic"
+        for line in lines[1:]:
+            if symbol in line:
+                vals[tag] = float(line.split()[-2]) * 1024.0   # avg KiB per dispatch -> bytes
                 break
     if len(vals) != 2:
-        return None
+        return None, "kernel %s not in the committed PMC passes" % symbol
     return {"bytes_per_launch": round(2.0 * vals["fetch"] + vals["write"]), "fetch_bytes_x2": round(2.0 * vals["fetch"]),
-            "write_bytes": round(vals["write"]), "source": "profiles/r01_pmc_{fetch,write}_size.txt (avg over all launches of this kernel)"}
+            "write_bytes": round(vals["write"]), "source": "profiles/r02_pmc_{fetch,write}_size.txt (same library digest; avg over all launches "
+            "of this kernel in `bench.py --roofline-only`)"}, None
 
 
-def cpu_baseline(sds, cfgs, H, W, evals, L, D):
-    """The fp32 CPU oracle (a port: the reference itself is not importable) timed on this box's host cores on a
-    bounded sample of the same workload: ONE CFG UNet evaluation (n=2) + VAE encode + EMASC + VAE decode for one 512x384 image;
-    images/s extrapolated as 1 / (evals * t_unet + 2 t_enc + t_emasc + t_dec)."""
-    from oracle import models as M  # test infrastructure: only used as the reported CPU baseline
+# ---------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the fp32 oracle (a port) on BASELINE configs[0], end to end
+# ---------------------------------------------------------------------------------------------------------------------------------
+def host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:   # respect the container's cgroup CPU quota (the GPU box shows 256 logical CPUs but grants 16)
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -122,26 +215,48 @@ def cpu_baseline(sds, cfgs, H, W, evals, L, D):
             cores = max(1, min(cores, int(int(q) / int(per))))
     except Exception:
         pass
+    return cores
+
+
+def cpu_baseline(sds, cfgs, runs, target_evals, scheduler):
+    """BASELINE configs[0] (B = 1, 20 scheduler steps, 512x384, CFG 7.5, EMASC on) END TO END through the fp32 CPU oracle (a port: the
+    reference itself is not importable here) on this box's host cores; median over `runs`.  images/s for the metric's
+    step count = 1 / (t_run + (target_evals - evals_20) * mean UNet evaluation time of the same run)."""
+    from oracle import models as M      # test infrastructure: only used as the reported CPU baseline
+    from oracle import pipeline as P
+    cores = host_cores()
     torch.set_num_threads(cores)
-    g = torch.Generator().manual_seed(0)
-    h, w = H // 8, W // 8
+    inp = P.synthetic_inputs(1, 512, 384, L=77, D=cfgs["unet"]["cross_attention_dim"])
+    totals, evals_t = [], []
+    n_evals = 0
     with torch.no_grad():
-        x = torch.randn((2, 31, h, w), generator=g)
-        ehs = torch.randn((2, L, D), generator=g)
-        t0 = time.time(); M.unet_forward(sds["unet"], cfgs["unet"], x, 481, ehs); t_unet = time.time() - t0
-        img = torch.rand((1, 3, H, W), generator=g) * 2 - 1
-        t0 = time.time(); mom, feats = M.vae_encode(sds["vae"], cfgs["vae"], img); t_enc = time.time() - t0
-        t0 = time.time(); sk = M.emasc_forward(sds["emasc"], feats[1:6]); t_em = time.time() - t0
-        z = torch.randn((1, 4, h, w), generator=g)
-        t0 = time.time(); M.vae_decode(sds["vae"], cfgs["vae"], z, sk, [1, 2, 3, 4, 5]); t_dec = time.time() - t0
-    per_image = evals * t_unet + 2 * t_enc + t_em + t_dec
+        for _ in range(max(1, runs)):
+            ts = []
+
+            def unet_fn(x, t, e):
+                t0 = time.time()
+                y = M.unet_forward(sds["unet"], cfgs["unet"], x, t, e)
+                ts.append(time.time() - t0)
+                return y
+
+            t0 = time.time()
+            P.tryon_pipeline(sds["unet"], cfgs["unet"], sds["vae"], cfgs["vae"], sds["emasc"], inp, num_inference_steps=20, guidance_scale=7.5,
+                             scheduler=scheduler, unet_fn=unet_fn)
+            totals.append(time.time() - t0)
+            evals_t.append(sum(ts) / len(ts))
+            n_evals = len(ts)
+    t_run, t_eval = statistics.median(totals), statistics.median(evals_t)
+    per_image = t_run + (target_evals - n_evals) * t_eval
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "fp32 torch-CPU oracle, full-size model: 1 CFG UNet eval (n=2, 64x48) %.2fs + VAE encode %.2fs + EMASC %.2fs + VAE decode %.2fs "
-                      "for one 512x384 image; extrapolated to %d evals + 2 encodes + EMASC + decode" % (t_unet, t_enc, t_em, t_dec, evals)}
+            "sample": "fp32 torch-CPU oracle, full-size model, BASELINE configs[0] end to end (B=1, 20 %s steps = %d CFG UNet evaluations, 512x384, EMASC on): "
+                      "%d run(s), median %.1f s (min %.1f s), %.2f s per CFG evaluation; images/s at the metric's %d evaluations = 1 / (t_run + %d x t_eval)"
+                      % (scheduler.upper(), n_evals, len(totals), t_run, min(totals), t_eval, target_evals, target_evals - n_evals),
+            "config0_seconds_per_image": round(t_run, 2), "config0_images_per_s": round(1.0 / t_run, 5)}
 
 
 def main():
     a = parse()
+    cfg = CONFIGS[a.config]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -152,15 +267,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+    B = a.batch or cfg["batch"]
+    H, W = a.height or cfg["H"], a.width or cfg["W"]
+    steps_inf = a.inference_steps or cfg["steps"]
+    scheduler = a.scheduler or cfg["scheduler"]
+    producers = cfg["producers"]
 
     import ladi_vton_amd as L
     from ladi_vton_amd import _lib, configs as C
-    from ladi_vton_amd.parallel import all_gather_images, to_uint8
+    from ladi_vton_amd.parallel import run_sharded
     ucfg, vcfg = (C.UNET_FULL, C.VAE_FULL) if a.size == "full" else (C.UNET_TINY, C.VAE_TINY)
     ecfg = C.emasc_for_vae(vcfg)
     cfgs = dict(unet=ucfg, vae=vcfg, emasc=ecfg)
     t_build = time.time()
-    want_cpu = (rank == 0 and world == 1 and not a.no_cpu_baseline and not a.roofline_only)
+    want_cpu = (rank == 0 and world == 1 and not a.no_cpu_baseline and not a.roofline_only and a.size == "full")
     if want_cpu:   # the CPU baseline needs the fp32 checkpoint on the host; otherwise stream it tensor by tensor
         sds = dict(unet=C.synth_state_dict(C.unet_shapes(ucfg), "unet."), vae=C.synth_state_dict(C.vae_shapes(vcfg), "vae."),
                    emasc=C.synth_state_dict(C.emasc_shapes(ecfg), "emasc."))
@@ -170,21 +290,40 @@ def main():
         unet = L.NativeUNet(ucfg, C.synth_items(C.unet_shapes(ucfg), "unet."))
         vae = L.NativeVAE(vcfg, C.synth_items(C.vae_shapes(vcfg), "vae."))
         emasc = L.NativeEMASC(ecfg, C.synth_items(C.emasc_shapes(ecfg), "emasc."))
-    sch = L.DDIMScheduler() if a.scheduler == "ddim" else L.PNDMScheduler()
+    vision = adapter = text = None
+    if producers and not a.roofline_only:
+        assert a.size == "full", "the producers are only wired for the released sizes"
+        vision = L.NativeCLIPVisionEncoder(C.VISION_FULL, C.synth_items(C.vision_shapes(C.VISION_FULL), "vision."))
+        adapter = L.NativeInversionAdapter(C.ADAPTER_FULL, C.synth_items(C.adapter_shapes(C.ADAPTER_FULL), "adapter."))
+        text = L.NativeCLIPTextEncoder(C.TEXT_FULL, C.synth_items(C.text_shapes(C.TEXT_FULL), "text."))
+    sch = L.DDIMScheduler() if scheduler == "ddim" else L.PNDMScheduler()
     pipe = L.StableDiffusionTryOnePipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, scheduler=sch, emasc=emasc,
                                            emasc_int_layers=[1, 2, 3, 4, 5])
     t_build = time.time() - t_build
-    B, H, W = a.batch, a.height, a.width
     Ltok, D = 77, ucfg["cross_attention_dim"]
-    inp = synthetic_device_inputs(B, H, W, Ltok, D, dev, seed=1234 + rank)
     global_B = B * world
+    lo = rank * B
+    local = make_rows(lo, lo + B, H, W, Ltok, D, dev)      # this rank's rows of the global batch, resident in HBM before the timed region
+    clip_mean = torch.tensor([0.48145466, 0.4578275, 0.40821073], device=dev).view(1, 3, 1, 1)
+    clip_std = torch.tensor([0.26862954, 0.26130258, 0.27577711], device=dev).view(1, 3, 1, 1)
+
+    def run_local(inp):
+        pe = inp["prompt_embeds"]
+        if producers:   # src/inference.py:267-295: in-shop cloth -> CLIP ViT-H/14 -> inversion adapter -> pseudo-word splice -> CLIP text encoder
+            img224 = L.resize_antialias((inp["cloth"].float() + 1) / 2, (224, 224)).clamp(0, 1)
+            feats = vision(((img224 - clip_mean) / clip_std).half()).last_hidden_state
+            words = adapter(feats).reshape(feats.shape[0], 16, -1)
+            pe = L.encode_text_word_embedding(text, inp["word_ids"], words, 16).last_hidden_state
+        return pipe._run_fused(inp["image"], inp["mask_image"], inp["pose_map"], inp["warped_cloth"], pe, inp["negative_prompt_embeds"],
+                               inp["noise_cloth"], inp["noise_latents"], inp["noise_masked"], H, W, steps_inf, 7.5, 1.0, False, not a.no_graph,
+                               return_device=True)
+
+    def rows(lo_, hi_):   # row materialiser of the global batch for run_sharded: this rank's rows are already resident
+        assert (lo_, hi_) == (lo, lo + B)
+        return local
 
     def one_step():
-        imgs = pipe._run_fused(inp["image"], inp["mask_image"], inp["pose_map"], inp["warped_cloth"], inp["prompt_embeds"],
-                               inp["negative_prompt_embeds"], inp["noise_cloth"], inp["noise_latents"], inp["noise_masked"], H, W,
-                               a.inference_steps, 7.5, 1.0, False, not a.no_graph, return_device=True)
-        u8 = to_uint8(imgs)
-        return all_gather_images(u8, global_B)   # the path's only collective (RCCL all-gather of decoded images)
+        return run_sharded(run_local, rows, batch=global_B)   # contiguous row shards + the path's only collective (RCCL all-gather of uint8 images)
 
     def fence():
         torch.cuda.synchronize()
@@ -194,7 +333,7 @@ def main():
 
     if a.roofline_only:
         # context for the stand-alone UNet forwards; one untimed forward first (per-shape tile measurement happens there)
-        e = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]]).contiguous()
+        e = torch.cat([local["negative_prompt_embeds"], local["prompt_embeds"]]).contiguous()
         unet.set_context(e)
         unet.time_forward(2 * B, H // 8, W // 8, 1)
         out = torch.zeros((global_B, H, W, 3), dtype=torch.uint8, device=dev)
@@ -213,73 +352,62 @@ def main():
     dt = float(tt.item())
     assert out.shape[0] == global_B and out.dtype == torch.uint8
     images_per_s = global_B * a.steps / dt if a.steps else 0.0
-    evals = a.inference_steps + (1 if a.scheduler == "pndm" else 0)
+    evals = steps_inf + (1 if scheduler == "pndm" else 0)
     lib = _lib.load()
     stage = (ctypes.c_float * 3)()
-    stage_ms = list(stage) if (pipe._tryon and lib.ladi_tryon_stage_ms(pipe._tryon, stage) == 0) else None
-    if stage_ms is not None:
-        stage_ms = [float(stage[i]) for i in range(3)]
+    stage_ms = [float(stage[i]) for i in range(3)] if (pipe._tryon and lib.ladi_tryon_stage_ms(pipe._tryon, stage) == 0) else None
+    flop_img = TRYON_FLOP_PER_IMAGE.get((scheduler, steps_inf, H)) if a.size == "full" and W * 4 == H * 3 else None
 
     roofline = None
     if rank == 0 and not a.no_roofline:
-        # dominant kernel = the MFMA implicit-GEMM family (conv3x3 / conv1x1 / linear = 88% of UNet FLOPs, UNet = 94% of the path).
-        # Per-launch HIP events on the launch stream around every igemm launch of CFG UNet forwards at the bench batch.
+        # dominant kernel = the kernel SYMBOL with the largest summed launch time inside CFG UNet forwards at the bench batch (UNet = 94 % of the
+        # path's FLOPs); per-launch HIP events on the launch stream around the main kernel of every implicit-GEMM launch.
         n = 2 * B
         h, w = H // 8, W // 8
         whole_ms = unet.time_forward(n, h, w, a.roofline_iters)
         lib.ladi_profile_igemm_enable(1)
         unet.time_forward(n, h, w, a.roofline_iters)   # 1 warm-up + roofline_iters timed forwards, all recorded
         lib.ladi_profile_igemm_enable(0)
-        prof = (ctypes.c_double * 192)()
-        lib.ladi_profile_igemm_collect(prof, 192)
-        names = {1: "igemm_kernel<2,2,2,4,32,3> (Q128xP256)", 2: "igemm_kernel<2,2,5,2,32,2> (Q320xP128)", 3: "igemm_kernel<2,2,2,2,32,3> (Q128xP128)",
-                 4: "igemm_kernel<2,2,2,1,32,3> (Q128xP64)", 5: "igemm_kernel<2,2,1,1,32,3> (Q64xP64)", 6: "igemm_kernel<2,2,4,2,32,3> (Q256xP128)"}
-        per = {}
-        names.update({7: "igemm_kernel<2,2,2,2,64,2> (Q128xP128 BK64)", 8: "igemm_kernel<2,2,2,4,64,2> (Q128xP256 BK64)", 9: "igemm_kernel<2,2,2,1,64,3> (Q128xP64 BK64)",
-                      10: "igemm_kernel<2,2,5,2,64,2> (Q320xP128 BK64)"})
-        names.update({11: "igemm_kernel<2,2,2,1,64,3> + split-K 2", 12: "igemm_kernel<2,2,2,1,64,3> + split-K 4", 13: "igemm_kernel<2,2,2,1,64,3> + split-K 8",
-                      14: "igemm_kernel<2,2,2,2,64,2> + split-K 2", 15: "igemm_kernel<2,2,2,2,64,2> + split-K 4"})
-        names.update({16: "igemm_kernel<2,2,1,1,32,4> (Q64xP64 NST4)", 17: "igemm_kernel<2,2,2,1,32,4> (Q128xP64 NST4)", 18: "igemm_kernel<2,2,2,2,32,4> (Q128xP128 NST4)",
-                      19: "igemm_kernel<2,4,2,2,32,3> (Q128xP256, 8 waves)", 20: "igemm_kernel<4,2,2,2,32,3> (Q256xP128, 8 waves)",
-                      21: "igemm_kernel<2,4,4,2,32,3> (Q256xP256, 8 waves)", 22: "igemm_kernel<2,4,5,2,64,2> (Q320xP256, 8 waves)"})
-        names.update({23: "linear_xs_kernel (64 px/wave, 1 channel slice)", 24: "linear_xs_kernel (64 px/wave, 2 channel slices)",
-                      25: "linear_xs_kernel (32 px/wave, 1 channel slice)", 26: "linear_xs_kernel (32 px/wave, 2 channel slices)",
-                      27: "linear_xs_kernel (32 px/wave, 5 channel slices)"})
-        names.update({28: "igemm_kernel<4,2,2,2,32,3> + split-K 4", 29: "igemm_kernel<4,2,2,2,32,3> + split-K 8",
-                      30: "igemm_kernel<2,4,2,2,32,3> + split-K 4", 31: "igemm_kernel<2,4,2,2,32,3> + split-K 8"})
-        names.update({32: "igemm8_kernel<5,2> (Q320xP256, phase-staggered)", 33: "igemm8_kernel<4,2> (Q256xP256, phase-staggered)",
-                      34: "igemm8_kernel<5,2> + split-K 2", 35: "igemm8_kernel<5,2> + split-K 4", 36: "igemm8_kernel<4,2> + split-K 2",
-                      37: "igemm8_kernel<4,2> + split-K 4", 38: "igemm8_kernel<4,2> + split-K 8"})
-        for c_ in range(1, 39):
+        prof = (ctypes.c_double * (3 * (NCFG + 1)))()
+        lib.ladi_profile_igemm_collect(prof, 3 * (NCFG + 1))
+        sym = {}
+        for c_ in range(1, NCFG + 1):
             ms, fl, cnt = prof[c_ * 3], prof[c_ * 3 + 1], prof[c_ * 3 + 2]
             if cnt > 0:
-                per[c_] = dict(kernel=names[c_], launches=int(cnt), avg_ms=ms / cnt, flop_per_launch=fl / cnt, tflops=fl / ms / 1e9)
-        dom = max(per, key=lambda k: per[k]["avg_ms"] * per[k]["launches"]) if per else None
-        if dom:
-            ach = per[dom]["tflops"]
+                s = sym.setdefault(SYMBOL.get(c_, "cfg%d" % c_), dict(ms=0.0, flop=0.0, launches=0, cfgs=[]))
+                s["ms"] += ms; s["flop"] += fl; s["launches"] += int(cnt); s["cfgs"].append(c_)
+        if sym:
+            dom = max(sym, key=lambda k: sym[k]["ms"])
+            d = sym[dom]
+            ach = d["flop"] / d["ms"] / 1e9
+            extra = ["--config", str(a.config), "--batch", str(B), "--height", str(H), "--width", str(W), "--size", a.size]
+            traffic, note = (traffic_measured(dom, extra) if a.measure_traffic and not a.roofline_only else traffic_committed(dom))
+            fwd_flop = UNET_FLOP_PER_SAMPLE_64x48 * n * (h * w / 3072.0) if a.size == "full" and (h, w) == (64, 48) else None
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4),
-                        "traffic": pmc_traffic(per[dom]["kernel"]), "kernel": per[dom]["kernel"], "avg_launch_ms": round(per[dom]["avg_ms"], 5),
-                        "flop_per_launch": per[dom]["flop_per_launch"], "launches_profiled": per[dom]["launches"],
+                        "traffic": traffic, "traffic_note": note, "kernel": dom, "tile_cfgs": d["cfgs"],
+                        "avg_launch_ms": round(d["ms"] / d["launches"], 5), "flop_per_launch": d["flop"] / d["launches"],
+                        "launches_profiled": d["launches"], "share_of_igemm_time": round(d["ms"] / prof[0], 4) if prof[0] > 0 else None,
                         "igemm_all_tflops": round(prof[1] / prof[0] / 1e9, 2) if prof[0] > 0 else None,
-                        "per_config": {per[k]["kernel"]: {"tflops": round(per[k]["tflops"], 1), "launches": per[k]["launches"],
-                                                          "avg_ms": round(per[k]["avg_ms"], 5)} for k in per},
+                        "per_symbol": {k: {"tflops": round(v["flop"] / v["ms"] / 1e9, 1), "launches": v["launches"], "avg_ms": round(v["ms"] / v["launches"], 5),
+                                           "total_ms": round(v["ms"], 3)} for k, v in sorted(sym.items(), key=lambda kv: -kv[1]["ms"])},
                         "unet_forward_ms": round(whole_ms, 3),
-                        "unet_forward_tflops": round(UNET_FLOP_PER_SAMPLE_64x48 * n * (h * w / 3072.0) / whole_ms / 1e9, 2) if a.size == "full" else None,
-                        "whole_path_frac": round(images_per_s / world * TRYON_FLOP_PER_IMAGE[a.scheduler] / 1e12 / PEAK_F16_TFLOPS, 4) if a.size == "full" and (H, W) == (512, 384) and a.inference_steps == 50 else None}
+                        "unet_forward_tflops": round(fwd_flop / whole_ms / 1e9, 2) if fwd_flop else None,
+                        "whole_path_frac": round(images_per_s / world * flop_img / 1e12 / PEAK_F16_TFLOPS, 4) if flop_img and a.steps else None}
     cpu = None
     if want_cpu:
         try:
-            cpu = cpu_baseline(sds, cfgs, H, W, evals, Ltok, D)
+            cpu = cpu_baseline(sds, cfgs, a.cpu_runs, evals, scheduler)
         except Exception as e:  # the baseline is reported, never required
-            cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+            cpu = {"value": None, "unit": "images/s", "cores": host_cores(), "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0:
         line = {
-            "metric": "try-on images/sec @%dx%d, %d %s steps" % (H, W, a.inference_steps, a.scheduler.upper()), "value": round(images_per_s, 4), "unit": "images/s",
+            "metric": "try-on images/sec @%dx%d, %d %s steps" % (H, W, steps_inf, scheduler.upper()), "value": round(images_per_s, 4), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1000.0, 2) if a.steps else None, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: VITON-HD-paired-like, batch %d per GPU, %d %s steps (%d UNet evals, CFG 7.5), %dx%d, "
-                                   "EMASC skips on, fp16 storage / fp32 accumulate, %s-size random-init checkpoint" % (B, a.inference_steps, a.scheduler.upper(), evals, H, W, a.size),
-                       "global_batch": global_B, "parallelism": "dp%d (batch sharding + RCCL all-gather of uint8 images)" % world,
+            "config": {"workload": "%s, %d %s steps (%d UNet evals, CFG 7.5), %dx%d, EMASC skips on, fp16 storage / fp32 accumulate, %s-size random-init "
+                                   "checkpoint" % (cfg["name"], steps_inf, scheduler.upper(), evals, H, W, a.size),
+                       "baseline_config_index": a.config, "batch_per_gpu": B, "global_batch": global_B, "producers_in_step": bool(producers),
+                       "parallelism": "dp%d (contiguous row shards of the global batch + RCCL all-gather of uint8 images)" % world,
                        "hipgraph": not a.no_graph},
             "stage_ms_rank0": stage_ms, "model_build_s": round(t_build, 1),
             "roofline": roofline, "cpu_baseline": cpu,

@@ -265,6 +265,16 @@ int ladi_op_attention_causal(const void* q, const void* k, const void* v, void* 
 int ladi_op_attention_generic(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq,
                               long long sk, long long sv, long long so, int n, int heads, int head_dim, int Nq, int Nk, float scale,
                               void* stream);
+/* ONE wide head (head_dim 128 / 256 / 512) — the VAE mid-block AttentionBlock (diffusers 0.14; src/models/vae.py:66-75 builds it through
+ * UNetMidBlock2D): flash-style, scores never materialised.  q, k: [n][N][ld]; vt = V TRANSPOSED [n][head_dim][ldvt >= Nk]; Nk % 4 == 0 */
+int ladi_op_attention_wide(const void* q, const void* k, const void* vt, void* o, int ldq, int ldk, int ldvt, int ldo, long long sq,
+                           long long sk, long long svt, long long so, int n, int head_dim, int Nq, int Nk, float scale, void* stream);
+/* glue between the TPS network and the refinement UNet (src/inference.py:242-260), NCHW planes, dtype 0 fp32 / 1 fp16 in and out:
+ * torchvision.transforms.functional.resize(x, size, BILINEAR, antialias=True) over `planes` = B*C images of H x W */
+int ladi_op_resize_bilinear_aa(const void* src, int dtype, int planes, int H, int W, void* dst, int out_dtype, int Ho, int Wo, void* stream);
+/* F.grid_sample(x [B,C,H,W], grid fp32 [B,Ho,Wo,2], mode bilinear, padding_mode "border", align_corners False) -> [B,C,Ho,Wo] */
+int ladi_op_grid_sample_border(const void* src, int dtype, int B, int C, int H, int W, const float* grid, int Ho, int Wo, void* dst,
+                               int out_dtype, void* stream);
 /* NHWC fp16 helpers of the refinement UNet: 2x2 max pooling, bilinear x2 upsampling with align_corners=True (C % 8 == 0) */
 int ladi_op_maxpool2(const void* src, int n, int H, int W, int C, void* dst, void* stream);
 int ladi_op_upsample2x_bilinear(const void* src, int n, int H, int W, int C, void* dst, void* stream);

@@ -136,6 +136,10 @@ SIGNATURES = {
                                          c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "ladi_op_attention_generic": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,
                                           c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "ladi_op_attention_wide": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,
+                                       c_int, c_int, c_int, c_int, c_float, _P]),
+    "ladi_op_resize_bilinear_aa": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
+    "ladi_op_grid_sample_border": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, _P]),
     "ladi_op_maxpool2": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "ladi_op_upsample2x_bilinear": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "ladi_op_softmax_rows": (c_int, [_P, c_int, c_int, c_float, _P, _P]),

@@ -43,14 +43,29 @@ def build(force=False, verbose=True):
         return LIB
     hipcc = _hipcc()
 
+    hdr = hashlib.sha256()
+    for f in HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            hdr.update(fh.read())
+    hdr.update(" ".join(FLAGS).encode())
+
     def compile_one(src):
+        # per-object stamp = sha256(source + every header + flags): an unchanged translation unit is not recompiled
         obj = os.path.join(OBJ, src + ".o")
+        h = hdr.copy()
+        with open(os.path.join(CSRC, src), "rb") as fh:
+            h.update(fh.read())
+        ostamp = obj + ".stamp"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == h.hexdigest():
+            return obj
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             sys.stderr.write(r.stderr)
+        with open(ostamp, "w") as fh:
+            fh.write(h.hexdigest())
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:

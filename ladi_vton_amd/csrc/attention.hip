@@ -394,6 +394,138 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Flash attention for ONE WIDE head (HD = 256 / 512): the VAE mid-block AttentionBlock (single head of d = C = 512 over the 64x48 or
+// 128x96 latent grid; diffusers 0.14 AttentionBlock).  Scores are never materialised (T^2 fp32 would be 57 MB per
+// sample at 512x384 and 0.9 GB at 1024x768).  A 512-wide head does not fit one wave (O^T alone = 256 accumulator registers), so the
+// head dimension is split over the 4 waves of a workgroup, which share 32 queries:
+//   * wave w owns d in [w*HD/4, (w+1)*HD/4): it holds that slice of Q as MFMA B fragments and the matching rows of O^T;
+//   * per tile of 32 keys every wave multiplies its K slice with its Q slice (partial S^T, swapped product as in flash_attn64), the four
+//     partial tiles are summed through a double-buffered LDS exchange (ONE barrier per tile), each wave then runs the same lane-local
+//     online softmax on the full scores and multiplies its own V^T rows with P.
+// V is consumed TRANSPOSED (vt[d][key], produced directly in that layout by the value projection GEMM), so its A fragments are plain
+// row segments; K / V^T fragments come straight from L2 (per sample K + V^T = 6 MB at T = 3072).  a.v = V^T, a.ldv = its row stride
+// (>= Nk), a.sv = per-sample stride.
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void flash_attn_wide_kernel(const AttnArgs a) {
+    constexpr int DS = HD / 4;               // head-dim slice of one wave
+    constexpr int DK = DS / 16;              // k16 steps of the partial S^T
+    constexpr int DB = DS / 32;              // 32-row blocks of this wave's O^T rows
+    __shared__ __attribute__((aligned(16))) float sx[2][4][4][64][4];   // [buffer][wave][reg / 4][lane][reg % 4] partial scores
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.y, qbase = blockIdx.x * 32;
+    const h16* __restrict__ qp = a.q + (size_t)n * a.sq + w * DS;
+    const h16* __restrict__ kp = a.k + (size_t)n * a.sk + w * DS;
+    const h16* __restrict__ vt = a.v + (size_t)n * a.sv + (size_t)(w * DS) * a.ldv;
+    const float qscale = a.scale * 1.4426950408889634f;
+    h16x8 qf[DK];
+    {
+        const int qrow = qbase + l31;
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) {
+            h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qrow < a.Nq) v = *reinterpret_cast<const h16x8*>(qp + (size_t)qrow * a.ldq + ks * 16 + hh * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] * qscale);
+            qf[ks] = v;
+        }
+    }
+    f32x16 o_acc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;
+    int buf = 0;
+    for (int key0 = 0; key0 < a.Nk; key0 += 32, buf ^= 1) {
+        // partial S^T[key][query] over this wave's slice of d
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        {
+            const int key = key0 + l31;
+            const bool valid = key < a.Nk;
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) {
+                h16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (valid) kf = *reinterpret_cast<const h16x8*>(kp + (size_t)key * a.ldk + ks * 16 + hh * 8);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(&sx[buf][w][g][lane][0]) = make_float4(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]);
+        __syncthreads();       // the only barrier of the tile: a wave writes buffer buf^1 next, which nobody can still be reading
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 t = *reinterpret_cast<const float4*>(&sx[buf][0][g][lane][0]);
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) {
+                const float4 u = *reinterpret_cast<const float4*>(&sx[buf][ww][g][lane][0]);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            s[4 * g] = t.x; s[4 * g + 1] = t.y; s[4 * g + 2] = t.z; s[4 * g + 3] = t.w;
+        }
+        // online softmax, lane-local per query (the two half-waves hold the two halves of a query's 32 keys)
+        float mt = -1.0e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            s[r] = (key < a.Nk) ? s[r] : -1.0e30f;
+            mt = fmaxf(mt, s[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        h16x8 pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
+            psum += p;
+            pf[r >> 3][r & 7] = (h16)p;
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+        // O^T[d][query] += V^T[d][key] P^T[key][query]; contraction order of a 16-key step = this lane's key set (matches pf)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int kofs = key0 + k2 * 16 + 4 * hh;
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const h16* vrow = vt + (size_t)(d * 32 + l31) * a.ldv + kofs;
+                h16x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+                if (kofs + 3 < a.Nk) lo = *reinterpret_cast<const h16x4*>(vrow);
+                if (kofs + 11 < a.Nk) hi = *reinterpret_cast<const h16x4*>(vrow + 8);
+                h16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                o_acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[k2], o_acc[d], 0, 0, 0);
+            }
+        }
+    }
+    const float inv = 1.f / (l_run + __shfl_xor(l_run, 32));
+    const int qrow = qbase + l31;
+    if (qrow < a.Nq) {
+        h16* op = a.o + (size_t)n * a.so + (size_t)qrow * a.ldo + w * DS;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (h16)(o_acc[d][4 * g + e] * inv);
+                *reinterpret_cast<h16x4*>(op + d * 32 + 8 * g + 4 * hh) = o;
+            }
+    }
+}
+
 // One wave per (sample, head): a single query row against Nk keys; head dim d <= 128 (lanes own d and d+64).
 __global__ __launch_bounds__(64) void attn_single_query_kernel(const h16* __restrict__ q, int ldq, const h16* __restrict__ k,
                                                                int ldk, const h16* __restrict__ v, int ldv,
@@ -460,6 +592,19 @@ int ladi_launch_attn_generic(const AttnArgs& a, int head_dim, hipStream_t st) {
         case 80: hipLaunchKernelGGL(attn_generic_kernel<80>, grid, dim3(64), 0, st, a); break;
         case 96: hipLaunchKernelGGL(attn_generic_kernel<96>, grid, dim3(64), 0, st, a); break;
         case 128: hipLaunchKernelGGL(attn_generic_kernel<128>, grid, dim3(64), 0, st, a); break;
+        default: return -2;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+int ladi_launch_attn_wide(const AttnArgs& a, int head_dim, hipStream_t st) {
+    // Nk % 4 == 0 keeps the 8-byte V^T row segments whole (masked per segment); heads == 1
+    if ((a.ldq & 7) || (a.ldk & 7) || (a.ldv & 3) || (a.ldo & 3) || a.Nk <= 0 || (a.Nk & 3) || a.Nq <= 0 || a.heads != 1 || a.causal) return -1;
+    dim3 grid((unsigned)((a.Nq + 31) / 32), (unsigned)a.n);
+    switch (head_dim) {
+        case 128: hipLaunchKernelGGL(flash_attn_wide_kernel<128>, grid, dim3(256), 0, st, a); break;
+        case 256: hipLaunchKernelGGL(flash_attn_wide_kernel<256>, grid, dim3(256), 0, st, a); break;
+        case 512: hipLaunchKernelGGL(flash_attn_wide_kernel<512>, grid, dim3(256), 0, st, a); break;
         default: return -2;
     }
     return hipGetLastError() == hipSuccess ? 0 : -11;

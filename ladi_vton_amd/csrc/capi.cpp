@@ -528,6 +528,21 @@ int ladi_op_attention_generic(const void* q, const void* k, const void* v, void*
     a.n = n; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
     return ladi_launch_attn_generic(a, head_dim, S(stream));
 }
+int ladi_op_attention_wide(const void* q, const void* k, const void* vt, void* o, int ldq, int ldk, int ldvt, int ldo, long long sq, long long sk,
+                           long long svt, long long so, int n, int head_dim, int Nq, int Nk, float scale, void* stream) {
+    AttnArgs a;
+    a.q = (const h16*)q; a.k = (const h16*)k; a.v = (const h16*)vt; a.o = (h16*)o;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldvt; a.ldo = ldo; a.sq = sq; a.sk = sk; a.sv = svt; a.so = so;
+    a.n = n; a.heads = 1; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+    return ladi_launch_attn_wide(a, head_dim, S(stream));
+}
+int ladi_op_resize_bilinear_aa(const void* src, int dtype, int planes, int H, int W, void* dst, int out_dtype, int Ho, int Wo, void* stream) {
+    return ladi_launch_resize_bilinear_aa(src, dtype == LADI_F32, planes, H, W, dst, out_dtype == LADI_F32, Ho, Wo, S(stream));
+}
+int ladi_op_grid_sample_border(const void* src, int dtype, int B, int C, int H, int W, const float* grid, int Ho, int Wo, void* dst,
+                               int out_dtype, void* stream) {
+    return ladi_launch_grid_sample_border(src, dtype == LADI_F32, B, C, H, W, grid, Ho, Wo, dst, out_dtype == LADI_F32, S(stream));
+}
 int ladi_op_maxpool2(const void* src, int n, int H, int W, int C, void* dst, void* stream) {
     return ladi_launch_maxpool2((const h16*)src, C, n, H, W, C, (h16*)dst, C, S(stream));
 }

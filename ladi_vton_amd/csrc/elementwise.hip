@@ -647,3 +647,97 @@ int ladi_launch_lat_pix_to_nchw(const float* src, int B, int hw, float* dst, hip
     hipLaunchKernelGGL(lat_pix_to_nchw_kernel, dim3((B * hw + 255) / 256), dim3(256), 0, st, src, B, hw, dst);
     return ok();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Glue of the warping module (src/inference.py:242-260): antialiased bilinear resize and border-padded grid_sample, NCHW planes.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float ld_any(const void* p, int f32, size_t i) {
+    return f32 ? reinterpret_cast<const float*>(p)[i] : (float)reinterpret_cast<const h16*>(p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, int f32, size_t i, float v) {
+    if (f32) reinterpret_cast<float*>(p)[i] = v; else reinterpret_cast<h16*>(p)[i] = (h16)v;
+}
+
+// torchvision.transforms.functional.resize(..., BILINEAR, antialias=True) == aten _upsample_bilinear2d_aa (align_corners=False):
+// separable triangle filter whose support is widened by the scale factor when down-sampling; per axis
+//   scale = in / out, support = max(scale, 1), centre = scale * (o + 0.5), taps [int(centre - support + 0.5), int(centre + support + 0.5))
+//   clipped to the image, weight = max(0, 1 - |(tap + 0.5 - centre) / max(scale, 1)|), normalised to sum 1.
+// One thread per output element evaluates the 2-D product of the two 1-D filters in fp32 (<= 7 x 7 taps for the 2.3x reductions here).
+__global__ __launch_bounds__(256) void resize_bilinear_aa_kernel(const void* __restrict__ src, int in_f32, int planes, int H, int W,
+                                                                 void* __restrict__ dst, int out_f32, int Ho, int Wo) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)planes * Ho * Wo;
+    if (idx >= total) return;
+    const int ox = (int)(idx % Wo), oy = (int)((idx / Wo) % Ho);
+    const size_t pl = idx / ((size_t)Wo * Ho);
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    const float supy = fmaxf(sy, 1.f), supx = fmaxf(sx, 1.f);
+    const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
+    const int y0 = max(0, (int)(cy - supy + 0.5f)), y1 = min(H, (int)(cy + supy + 0.5f));
+    const int x0 = max(0, (int)(cx - supx + 0.5f)), x1 = min(W, (int)(cx + supx + 0.5f));
+    const float iy = 1.f / supy, ix = 1.f / supx;
+    float wys = 0.f, wxs = 0.f;
+    for (int y = y0; y < y1; ++y) wys += fmaxf(0.f, 1.f - fabsf(((float)y - cy + 0.5f) * iy));
+    for (int x = x0; x < x1; ++x) wxs += fmaxf(0.f, 1.f - fabsf(((float)x - cx + 0.5f) * ix));
+    const size_t base = pl * (size_t)H * W;
+    float acc = 0.f;
+    for (int y = y0; y < y1; ++y) {
+        const float wy = fmaxf(0.f, 1.f - fabsf(((float)y - cy + 0.5f) * iy));
+        float row = 0.f;
+        for (int x = x0; x < x1; ++x)
+            row += fmaxf(0.f, 1.f - fabsf(((float)x - cx + 0.5f) * ix)) * ld_any(src, in_f32, base + (size_t)y * W + x);
+        acc += wy * row;
+    }
+    st_any(dst, out_f32, idx, acc / (wys * wxs));
+}
+
+// F.grid_sample(x, grid, mode="bilinear", padding_mode="border", align_corners=False) (src/inference.py:260): x = ((g + 1) * size - 1) / 2
+// clipped to [0, size - 1]; the four corners are weighted bilinearly, corners outside the image (only possible with zero weight after
+// the clip) are skipped.  One thread per output pixel walks the channels (the grid sample is shared by them).
+__global__ __launch_bounds__(256) void grid_sample_border_kernel(const void* __restrict__ src, int in_f32, int B, int C, int H, int W,
+                                                                 const float* __restrict__ grid, int Ho, int Wo,
+                                                                 void* __restrict__ dst, int out_f32) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)B * Ho * Wo;
+    if (idx >= total) return;
+    const size_t b = idx / ((size_t)Ho * Wo), pix = idx % ((size_t)Ho * Wo);
+    const float gx = grid[idx * 2], gy = grid[idx * 2 + 1];
+    float x = ((gx + 1.f) * (float)W - 1.f) * 0.5f, y = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    x = fminf(fmaxf(x, 0.f), (float)(W - 1));
+    y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = x - xf, ty = y - yf;
+    const float wnw = (1.f - tx) * (1.f - ty), wne = tx * (1.f - ty), wsw = (1.f - tx) * ty, wse = tx * ty;
+    const bool inx1 = x1 < W, iny1 = y1 < H;
+    for (int c = 0; c < C; ++c) {
+        const size_t base = (b * C + c) * (size_t)H * W;
+        float v = wnw * ld_any(src, in_f32, base + (size_t)y0 * W + x0);
+        if (inx1) v += wne * ld_any(src, in_f32, base + (size_t)y0 * W + x1);
+        if (iny1) v += wsw * ld_any(src, in_f32, base + (size_t)y1 * W + x0);
+        if (inx1 && iny1) v += wse * ld_any(src, in_f32, base + (size_t)y1 * W + x1);
+        st_any(dst, out_f32, (b * C + c) * (size_t)Ho * Wo + pix, v);
+    }
+}
+
+}  // namespace
+
+int ladi_launch_resize_bilinear_aa(const void* src, int in_f32, int planes, int H, int W, void* dst, int out_f32, int Ho, int Wo,
+                                   hipStream_t st) {
+    if (planes <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return -1;
+    const size_t total = (size_t)planes * Ho * Wo;
+    hipLaunchKernelGGL(resize_bilinear_aa_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, in_f32, planes, H, W, dst,
+                       out_f32, Ho, Wo);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+int ladi_launch_grid_sample_border(const void* src, int in_f32, int B, int C, int H, int W, const float* grid, int Ho, int Wo, void* dst,
+                                   int out_f32, hipStream_t st) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return -1;
+    const size_t total = (size_t)B * Ho * Wo;
+    hipLaunchKernelGGL(grid_sample_border_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, in_f32, B, C, H, W, grid,
+                       Ho, Wo, dst, out_f32);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}

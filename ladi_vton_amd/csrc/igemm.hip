@@ -569,11 +569,11 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         case 33: rc = ladi_launch_igemm8(a, 4, 2, batch_l, st); break;
         default: rc = -7;
     }
+    if (prof) { (void)hipEventRecord(rec.e1, st); g_recs.push_back(rec); }   // the main kernel only (the reduce pass is its own symbol)
     if (rc == 0 && split > 1) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((full.P + 31) / 32), (unsigned)((full.Q + 63) / 64)), dim3(256), 0, st, ws, split, full);
         if (hipGetLastError() != hipSuccess) rc = -11;
     }
-    if (prof) { (void)hipEventRecord(rec.e1, st); g_recs.push_back(rec); }
     return rc;
 }
 

@@ -51,6 +51,9 @@ struct AttnArgs {
 int ladi_launch_flash_attn64(const AttnArgs& a, hipStream_t st);
 // heads of dimension 64 / 80 / 96 / 128 at column offset h*head_dim (CLIP ViT-H vision tower: 80); non-causal
 int ladi_launch_attn_generic(const AttnArgs& a, int head_dim, hipStream_t st);
+// ONE wide head (head_dim 128 / 256 / 512: the VAE AttentionBlock), flash-style; a.v = V^T [head_dim][Nk] (row stride a.ldv),
+// a.heads must be 1, Nk % 4 == 0
+int ladi_launch_attn_wide(const AttnArgs& a, int head_dim, hipStream_t st);
 // single query per (sample, head): q [n][ldq], k/v [n][Nk][ld], generic head dim d <= 128
 int ladi_launch_attn_single_query(const h16* q, int ldq, const h16* k, int ldk, const h16* v, int ldv, h16* o, int ldo,
                                   int n, int heads, int d, int Nk, long long sk, long long sv, float scale, hipStream_t st);
@@ -123,6 +126,13 @@ int ladi_launch_tps_grid(const float* coor, const float* inv, const float* ctrl,
 // refinement UNet helpers (NHWC fp16, C % 8 == 0): 2x2 max pooling; bilinear x2 upsampling with align_corners=True
 int ladi_launch_maxpool2(const h16* src, int lds_, int n, int H, int W, int C, h16* dst, int ldd, hipStream_t st);
 int ladi_launch_upsample2x_bilinear_ac(const h16* src, int lds_, int n, int H, int W, int C, h16* dst, int ldd, hipStream_t st);
+// glue of the warping module (src/inference.py:242-260), NCHW planes, fp32 or fp16 in / out:
+// torchvision resize(BILINEAR, antialias=True) == aten _upsample_bilinear2d_aa (align_corners=False)
+int ladi_launch_resize_bilinear_aa(const void* src, int in_f32, int planes, int H, int W, void* dst, int out_f32, int Ho, int Wo,
+                                   hipStream_t st);
+// F.grid_sample(x, grid, bilinear, padding_mode="border", align_corners=False); grid fp32 [B][Ho][Wo][2] (x, y)
+int ladi_launch_grid_sample_border(const void* src, int in_f32, int B, int C, int H, int W, const float* grid, int Ho, int Wo, void* dst,
+                                   int out_f32, hipStream_t st);
 // ViT patch rows for the patch-embedding GEMM: out [B][1 + (S/ps)^2][KP] fp16, row 0 and the padding columns zero
 int ladi_launch_patchify(const void* px, int in_f32, int B, int S, int ps, int KP, h16* out, hipStream_t st);
 int ladi_launch_gather_rows(const h16* src, const int* rows, int n, int H, h16* dst, hipStream_t st);

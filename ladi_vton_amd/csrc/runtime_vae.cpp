@@ -116,9 +116,11 @@ struct VF {
         c.ar->release(mk);
         return out;
     }
-    // diffusers AttentionBlock (single head, d = C): materialised scores through three batched MFMA GEMMs
+    // diffusers AttentionBlock (single head, d = C).  C = 128 / 256 / 512 (every released / test configuration): flash attention over
+    // the wide head, scores never leave the chip (flash_attn_wide_kernel); other widths: materialised scores through batched GEMMs.
     Act attn(const VAEAttn& at, const Act& x) {
         const int n = x.n, T = x.h * x.w, C = at.C;
+        const bool flash = (C == 128 || C == 256 || C == 512) && (T % 4 == 0);
         Act out = new_act_with_stats(c, x.n, x.h, x.w, C);
         const size_t mk = c.ar->mark();
         Act g = group_norm(c, at.gn, x, nullptr, v.cfg.groups, v.cfg.eps, 0);
@@ -126,11 +128,11 @@ struct VF {
         ConvOpt op;
         Act qk = conv2d(c, at.qk, tok, nullptr, op);                 // [n*T][2C]
         h16* vt = c.alloc_h16((size_t)n * C * T);                    // V^T [n][C][T]
-        float* S = c.alloc_f32((size_t)n * T * T);
-        h16* P = c.alloc_h16((size_t)n * T * T);
+        float* S = flash ? nullptr : c.alloc_f32((size_t)n * T * T);
+        h16* P = flash ? nullptr : c.alloc_h16((size_t)n * T * T);
         Act o = c.new_act(n, T, 1, C);
         if (!c.dry()) {
-            if (T % 64) throw std::runtime_error("VAE attention: tokens must be a multiple of 64");
+            if (!flash && (T % 64)) throw std::runtime_error("VAE attention: tokens must be a multiple of 64");
             IGemmArgs a;
             // V^T[b] = Wv * Xn[b]^T + bv   (pixel operand = Wv rows, weight operand = tokens)
             std::memset(&a, 0, sizeof(a));
@@ -138,6 +140,14 @@ struct VF {
             a.ksize = 1; a.stride = 1; a.W = g.p; a.Q = T; a.K = C; a.ldw = g.ld; a.bs_w = (long long)T * g.ld;
             a.bias = at.v.b; a.bias_per_pixel = 1; a.out_scale = 1.f; a.out = vt; a.ldo = T; a.bs_out = (long long)C * T;
             c.check(ladi_launch_igemm(a, n, 0, c.st), "igemm(vT)");
+            if (flash) {
+                AttnArgs fa;
+                fa.q = qk.p; fa.k = qk.p + C; fa.v = vt; fa.o = o.p;
+                fa.ldq = 2 * C; fa.ldk = 2 * C; fa.ldv = T; fa.ldo = C;
+                fa.sq = (long long)T * 2 * C; fa.sk = fa.sq; fa.sv = (long long)C * T; fa.so = (long long)T * C;
+                fa.n = n; fa.heads = 1; fa.Nq = T; fa.Nk = T; fa.scale = 1.f / std::sqrt((float)C);
+                c.check(ladi_launch_attn_wide(fa, C, c.st), "attn_wide");
+            } else {
             // S[b] = Q[b] K[b]^T (fp32)
             std::memset(&a, 0, sizeof(a));
             a.src0 = qk.p; a.C0 = C; a.ld0 = 2 * C; a.bs_src0 = (long long)T * 2 * C; a.Hs = T; a.Ws = 1; a.Ho = T; a.Wo = 1; a.P = T;
@@ -151,6 +161,7 @@ struct VF {
             a.ksize = 1; a.stride = 1; a.W = vt; a.Q = C; a.K = T; a.ldw = T; a.bs_w = (long long)C * T;
             a.out_scale = 1.f; a.out = o.p; a.ldo = C; a.bs_out = (long long)T * C;
             c.check(ladi_launch_igemm(a, n, 0, c.st), "igemm(PV)");
+            }
             // proj_attn + residual
             std::memset(&a, 0, sizeof(a));
             a.src0 = o.p; a.C0 = C; a.ld0 = C; a.Hs = n * T; a.Ws = 1; a.Ho = n * T; a.Wo = 1; a.P = n * T;

@@ -45,10 +45,19 @@ def all_gather_images(local_u8, batch, group=None):
     return torch.cat(parts, dim=0)
 
 
-def run_sharded(run_local, inputs, group=None):
-    """run_local(local_inputs) -> [b_r, H, W, 3] float images in [0,1] on this rank's device; returns the gathered uint8 batch"""
+def run_sharded(run_local, inputs, group=None, batch=None):
+    """run_local(local_inputs) -> [b_r, H, W, 3] float images in [0,1] on this rank's device; returns the gathered uint8 batch.
+    `inputs` is the GLOBAL batch: either a dict of [B, ...] tensors (sliced here), or a callable rows(lo, hi) -> dict that materialises
+    rows [lo, hi) of the global batch (same values as slicing it; `batch` = B) so that a rank never builds the other ranks' samples."""
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    local, _ = shard_inputs(inputs, rank, world)
+    if callable(inputs):
+        if batch is None:
+            raise ValueError("`batch` (global batch size) is required with a row materialiser")
+        lo, hi = shard_bounds(batch, rank, world)
+        local = inputs(lo, hi)
+    else:
+        batch = inputs["image"].shape[0]
+        local, _ = shard_inputs(inputs, rank, world)
     imgs = run_local(local)
-    return all_gather_images(to_uint8(imgs), inputs["image"].shape[0], group)
+    return all_gather_images(to_uint8(imgs), batch, group)

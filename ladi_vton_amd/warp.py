@@ -90,3 +90,56 @@ class NativeTPS(_Shim):
         coor = torch.empty((B, N, 2), dtype=torch.float32, device=self.device)
         check(self.lib.ladi_tps_forward(self.h, ptr(a), ptr(b), dtype_code(a), B, ptr(grid), ptr(coor), stream_ptr()), "ladi_tps_forward")
         return grid, coor, None, None, None, None, None, None
+
+
+def resize_antialias(x, size):
+    """torchvision.transforms.functional.resize(x, size, InterpolationMode.BILINEAR, antialias=True) on the device (src/inference.py:242-258,
+    267-268): x [B, C, H, W] fp32 / fp16 -> [B, C, size[0], size[1]], same dtype."""
+    if x.dim() != 4:
+        raise ValueError("expected a [B, C, H, W] tensor")
+    lib = _lib.load()
+    xin = x.to(torch.device("cuda", torch.cuda.current_device()))
+    if xin.dtype not in (torch.float16, torch.float32):
+        xin = xin.float()
+    xin = xin.contiguous()
+    B, C, H, W = xin.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    out = torch.empty((B, C, Ho, Wo), dtype=xin.dtype, device=xin.device)
+    check(lib.ladi_op_resize_bilinear_aa(ptr(xin), dtype_code(xin), B * C, H, W, ptr(out), dtype_code(out), Ho, Wo, stream_ptr()),
+          "ladi_op_resize_bilinear_aa")
+    return out
+
+
+def grid_sample_border(x, grid):
+    """F.grid_sample(x, grid, padding_mode="border") (bilinear, align_corners=False; src/inference.py:260): x [B, C, H, W], grid
+    [B, Ho, Wo, 2] in [-1, 1] (x, y) -> [B, C, Ho, Wo] of x's dtype."""
+    if x.dim() != 4 or grid.dim() != 4 or grid.shape[-1] != 2 or grid.shape[0] != x.shape[0]:
+        raise ValueError("expected x [B, C, H, W] and grid [B, Ho, Wo, 2]")
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xin = x.to(dev)
+    if xin.dtype not in (torch.float16, torch.float32):
+        xin = xin.float()
+    xin = xin.contiguous()
+    g = grid.to(device=dev, dtype=torch.float32).contiguous()
+    B, C, H, W = xin.shape
+    Ho, Wo = g.shape[1], g.shape[2]
+    out = torch.empty((B, C, Ho, Wo), dtype=xin.dtype, device=dev)
+    check(lib.ladi_op_grid_sample_border(ptr(xin), dtype_code(xin), B, C, H, W, ptr(g), Ho, Wo, ptr(out), dtype_code(out), stream_ptr()),
+          "ladi_op_grid_sample_border")
+    return out
+
+
+def warp_cloth(tps, refinement, cloth, im_mask, pose_map, low_size=(256, 192)):
+    """The warping stage of src/inference.py:239-266 on the native kernels end to end: antialiased down-sampling of cloth / agnostic
+    inputs, TPS matching network, grid up-sampling, border grid_sample and the refinement UNet.  Returns the refined warped cloth
+    [B, 3, H, W] (fp32, clamped to [-1, 1]) and the TPS control points."""
+    H, W = cloth.shape[-2:]
+    low_cloth = resize_antialias(cloth, low_size)
+    agnostic = torch.cat([resize_antialias(im_mask, low_size), resize_antialias(pose_map, low_size)], 1)
+    low_grid, theta = tps(low_cloth.to(torch.float32), agnostic.to(torch.float32))[:2]
+    grid = resize_antialias(low_grid.permute(0, 3, 1, 2), (H, W)).permute(0, 2, 3, 1)
+    warped = grid_sample_border(cloth.to(torch.float32), grid)
+    dev = warped.device
+    refined = refinement(torch.cat([im_mask.to(dev, torch.float32), pose_map.to(dev, torch.float32), warped], 1))
+    return refined.clamp(-1, 1), theta

@@ -390,6 +390,13 @@ def run_local(loc):   # stand-in for the per-rank pipeline: a per-sample functio
 out = run_sharded(run_local, inputs)
 ref = ((inputs["image"] * inputs["noise"][:, :3]).permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8)
 assert out.shape == ref.shape and torch.equal(out, ref), (rank, out.shape)
+# the row-materialiser form (what bench.py uses: a rank only ever builds its own rows of the global batch) gives the same batch
+seen = []
+def rows(lo, hi):
+    seen.append((lo, hi))
+    return {k: (v[lo:hi] if isinstance(v, torch.Tensor) else v) for k, v in inputs.items()}
+out2 = run_sharded(run_local, rows, batch=B)
+assert torch.equal(out2, ref) and seen == [shard_bounds(B, rank, world)], (rank, seen)
 dist.barrier(); dist.destroy_process_group()
 print("OK", rank)
 """

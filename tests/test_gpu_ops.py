@@ -547,3 +547,53 @@ def test_assemble_unet_input(lib, cfg, cloth):
     else:
         assert torch.equal(got[..., :C], cond)
     assert float(got[..., C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("hd,Nq,Nk", [(512, 96, 96), (512, 200, 332), (128, 64, 36), (256, 33, 100)])
+def test_flash_attention_wide_head(lib, hd, Nq, Nk):
+    """single wide head (the VAE AttentionBlock, d = C = 512): head dim split over the 4 waves of a workgroup, partial scores summed
+    through LDS; ragged query / key counts; V consumed transposed.  vs torch softmax(QK^T / sqrt(d)) V in fp32; tolerance 3e-3"""
+    n = 2
+    q, k, v = _rand((n, Nq, hd), 95), _rand((n, Nk, hd), 96), _rand((n, Nk, hd), 97)
+    k[0, 5] *= 3.0                                              # one dominant key: the running maximum jumps mid-sequence
+    ref = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(hd), dim=-1) @ v
+    Q, K = q.half().to(U.dev()), k.half().to(U.dev())
+    VT = v.half().transpose(1, 2).contiguous().to(U.dev())       # [n][hd][Nk]
+    O = torch.zeros((n, Nq, hd), dtype=torch.float16, device=U.dev())
+    rc = lib.ladi_op_attention_wide(ptr(Q), ptr(K), ptr(VT), ptr(O), hd, hd, Nk, hd, Nq * hd, Nk * hd, hd * Nk, Nq * hd, n, hd, Nq, Nk,
+                                    1.0 / math.sqrt(hd), stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert U.rel_l2(O.float().cpu(), ref) < 3e-3, U.rel_l2(O.float().cpu(), ref)
+
+
+# --------------------------------------------------------------------------------------------------------------- warping glue (§8 f-3)
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("hw,size", [((512, 384), (256, 192)), ((512, 384), (224, 224)), ((256, 192), (512, 384)), ((37, 53), (16, 20))])
+def test_resize_antialias_matches_aten(lib, f16, hw, size):
+    """torchvision resize(BILINEAR, antialias=True) == F.interpolate(mode='bilinear', antialias=True) (src/inference.py:242-258,267): the three
+    reductions / the grid up-sampling the reference performs, plus a non-integer ragged case; fp32 tolerance 2e-5 abs, fp16 2e-3"""
+    import ladi_vton_amd as L
+    x = (torch.rand((2, 3) + hw, generator=torch.Generator().manual_seed(70)) * 2 - 1)
+    x = x.half().float() if f16 else x
+    ref = F.interpolate(x, size=size, mode="bilinear", antialias=True, align_corners=False)
+    got = L.resize_antialias(x.half().to(U.dev()) if f16 else x.to(U.dev()), size)
+    torch.cuda.synchronize()
+    assert got.dtype == (torch.float16 if f16 else torch.float32) and tuple(got.shape) == tuple(ref.shape)
+    assert (got.float().cpu() - ref).abs().max() <= (2e-3 if f16 else 2e-5), (got.float().cpu() - ref).abs().max()
+
+
+def test_grid_sample_border_matches_torch(lib):
+    """F.grid_sample(..., padding_mode='border') (src/inference.py:260) incl. samples outside [-1, 1] (clamped to the border) and exactly on
+    the last pixel; fp32, abs tolerance 2e-5"""
+    import ladi_vton_amd as L
+    g = torch.Generator().manual_seed(71)
+    x = torch.rand((2, 3, 40, 28), generator=g) * 2 - 1
+    grid = torch.rand((2, 64, 48, 2), generator=g) * 2.6 - 1.3
+    grid[0, 0, 0] = torch.tensor([1.0, 1.0]); grid[0, 0, 1] = torch.tensor([-1.0, -1.0]); grid[0, 0, 2] = torch.tensor([27.0 / 28.0, 39.0 / 40.0])
+    ref = F.grid_sample(x, grid, padding_mode="border", align_corners=False)
+    got = L.grid_sample_border(x.to(U.dev()), grid.to(U.dev()))
+    torch.cuda.synchronize()
+    assert (got.cpu() - ref).abs().max() <= 2e-5, (got.cpu() - ref).abs().max()
+    got16 = L.grid_sample_border(x.half().to(U.dev()), grid.to(U.dev()))
+    assert got16.dtype == torch.float16 and (got16.float().cpu() - F.grid_sample(x.half().float(), grid, padding_mode="border", align_corners=False)).abs().max() <= 2e-3
