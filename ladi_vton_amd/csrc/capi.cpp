@@ -208,6 +208,7 @@ int ladi_vae_decode(ladi_vae* v, const float* z, int B, int h, int w, const void
                 const int sh[5] = {H, H, H / 2, H / 4, H / 8}, sw[5] = {W, W, W / 2, W / 4, W / 8};
                 const int sc[5] = {V.cfg.boc[0], V.cfg.boc[1], V.cfg.boc[2], V.cfg.boc[3], V.cfg.boc[3]};
                 for (int i = 0; i < 5; ++i) {
+                    if (!skips_dev[i]) continue;                      // slot omitted by the int_layers selection
                     skips[i].p = reinterpret_cast<h16*>(const_cast<void*>(skips_dev[i]));
                     skips[i].n = B; skips[i].h = sh[i]; skips[i].w = sw[i]; skips[i].c = sc[i]; skips[i].ld = sc[i];
                 }

@@ -32,6 +32,9 @@
 #include <cstdlib>
 #include <algorithm>
 #include <utility>
+#include <dlfcn.h>
+
+int ladi_igemm_num_cfgs();
 
 namespace {
 
@@ -367,17 +370,33 @@ bool g_autotune = true;
 std::unordered_map<TuneKey, int, TuneHash> g_tuned;
 // optional persistence of the measured choices across processes (LADI_TUNE_CACHE=<file>): one line per problem shape
 bool g_cache_loaded = false;
-void tune_cache_load() {
-    if (g_cache_loaded) return;
-    g_cache_loaded = true;
-    const char* path = getenv("LADI_TUNE_CACHE");
-    if (!path) return;
+void tune_cache_read(const char* path) {
     FILE* f = fopen(path, "r");
     if (!f) return;
     TuneKey k; int cfg;
-    while (fscanf(f, "%d %d %d %d %d %d %d %d %d", &k.P, &k.Q, &k.K, &k.C0, &k.C1, &k.Wo, &k.flags, &k.batch, &cfg) == 9)
-        if (cfg >= 1 && cfg <= 64) g_tuned[k] = cfg;
+    char line[256];
+    while (fgets(line, sizeof(line), f)) {
+        if (line[0] == '#') continue;
+        if (sscanf(line, "%d %d %d %d %d %d %d %d %d", &k.P, &k.Q, &k.K, &k.C0, &k.C1, &k.Wo, &k.flags, &k.batch, &cfg) == 9 && cfg >= 1 && cfg <= NCFG)
+            g_tuned[k] = cfg;
+    }
     fclose(f);
+}
+// Selections are loaded from (1) the table shipped next to the library (tune_gfx950.txt: the choices measured on MI355X for the layer
+// shapes of the released model at the BASELINE batch sizes, so that those runs pick the same tiles -- hence the same summation order and
+// the same last bits -- in every process) and (2) LADI_TUNE_CACHE=<file> (read, and appended to when a new shape is measured).
+void tune_cache_load() {
+    if (g_cache_loaded) return;
+    g_cache_loaded = true;
+    if (!getenv("LADI_TUNE_NO_SHIPPED")) {
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void*>(&ladi_igemm_num_cfgs), &info) && info.dli_fname) {
+            std::string p(info.dli_fname);
+            const size_t s = p.find_last_of('/');
+            tune_cache_read(((s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/tune_gfx950.txt").c_str());
+        }
+    }
+    if (const char* path = getenv("LADI_TUNE_CACHE")) tune_cache_read(path);
 }
 void tune_cache_append(const TuneKey& k, int cfg) {
     const char* path = getenv("LADI_TUNE_CACHE");

@@ -203,23 +203,25 @@ Act VAE::encode(Ctx& c, const Act& x, Act feats[5]) {
 Act VAE::decode(Ctx& c, const Act& z, const Act* skips) {
     VF f{c, *this};
     const int L = cfg.layers_per_block;
+    // slot i = EMASC output for encoder feature idx i+1; a slot without a tensor is an int_layers selection that omits it (vae.py:190-205)
+    auto sk = [&](int i) -> const Act* { return (skips && skips[i].p) ? &skips[i] : nullptr; };
     ConvOpt o; o.stats = true;
     Act h = conv2d(c, d_conv_in, z, nullptr, o);
     h = f.res(d_mid[0], h, nullptr);
     h = f.attn(d_attn, h);
     // vae.py:191-194: sample += reversed(feats)[i] before up_block i  -> folded into the producing epilogue
-    h = f.res(d_mid[1], h, skips ? &skips[4] : nullptr);
+    h = f.res(d_mid[1], h, sk(4));
     int ri = 0;
     for (int i = 0; i < 4; ++i) {
         for (int j = 0; j < L + 1; ++j) h = f.res(d_res[ri++], h, nullptr);
         if (i < 3) {
             ConvOpt ou; ou.ups = 1; ou.stats = true;
-            if (skips) ou.res0 = &skips[3 - i];
+            ou.res0 = sk(3 - i);
             h = conv2d(c, d_up[i], h, nullptr, ou);
         }
     }
     // vae.py:200-205: conv_norm_out -> SiLU -> (+ feats for int layer 1) -> conv_out
-    Act g = group_norm(c, d_norm_out, h, nullptr, cfg.groups, cfg.eps, 1, skips ? &skips[0] : nullptr);
+    Act g = group_norm(c, d_norm_out, h, nullptr, cfg.groups, cfg.eps, 1, sk(0));
     ConvOpt oc; oc.out_ld = 4;
     return conv2d(c, d_conv_out, g, nullptr, oc);
 }

@@ -229,10 +229,18 @@ class NativeVAE(_Base):
         arr = None
         keep = []
         if intermediate_features:
-            if list(int_layers or []) != [1, 2, 3, 4, 5] or len(intermediate_features) != 5:
-                raise NotImplementedError("native decode supports emasc_int_layers == [1, 2, 3, 4, 5]")
+            # Decoder.forward (vae.py:188-205) zips the REVERSED list with the up blocks and adds layer 1 after conv_norm_out: the shapes
+            # only line up when int_layers is a contiguous run ending at 5 ([1..5], [2..5], [3..5], [4, 5], [5]); anything else fails in
+            # the reference with a tensor-shape error
+            layers = list(int_layers or [])
+            if not layers or layers != list(range(layers[0], 6)) or layers[0] < 1 or len(intermediate_features) != len(layers):
+                raise ValueError("int_layers must be a contiguous run ending at 5 with one feature per layer (got %r with %d features): "
+                                 "the reference's Decoder.forward cannot add any other selection" % (int_layers, len(intermediate_features)))
             keep = [_nhwc_buffer(f) for f in intermediate_features]
-            arr = (c_void_p * 5)(*[k.data_ptr() for k in keep])
+            slots = [None] * 5
+            for layer, k in zip(layers, keep):
+                slots[layer - 1] = k.data_ptr()
+            arr = (c_void_p * 5)(*slots)
             intermediate_features.reverse()  # the reference reverses the caller's list in place (vae.py:190)
         out = torch.empty((B, self.cfg["out_channels"], 8 * h, 8 * w), dtype=z.dtype if z.dtype in (torch.float16, torch.float32) else torch.float32,
                           device=z.device)

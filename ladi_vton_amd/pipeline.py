@@ -105,6 +105,14 @@ class StableDiffusionTryOnePipeline:
             raise ValueError("Mask should be in [0, 1] range")
 
     def _draw(self, shape, generator, dtype, device):
+        """diffusers randn_tensor: one draw of the whole batch, or -- for a LIST of generators (tryon_pipe.py:443-455,463-470) -- one
+        [1, ...] draw per sample from that sample's generator"""
+        if isinstance(generator, (list, tuple)):
+            if len(generator) != shape[0]:
+                raise ValueError("You have passed a list of generators of length %d, but requested an effective batch size of %d."
+                                 % (len(generator), shape[0]))
+            parts = [torch.randn((1,) + tuple(shape[1:]), generator=g, device=g.device, dtype=dtype).to(device) for g in generator]
+            return torch.cat(parts, dim=0).to(torch.float32)
         gdev = generator.device if generator is not None else device
         return torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device=device, dtype=torch.float32)
 

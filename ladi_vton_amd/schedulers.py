@@ -57,14 +57,21 @@ class DDIMScheduler(_SchedulerBase):
         ts = self._native_timesteps(num_inference_steps)
         self.timesteps = torch.tensor(ts, dtype=torch.int64, device=device)
 
-    def step(self, model_output, timestep, sample, eta=0.0, generator=None, **kw):
-        if eta != 0.0:
-            raise NotImplementedError("eta != 0 is not supported (the reference always uses eta = 0)")
+    def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None, variance_noise=None, **kw):
+        """DDIM eq. (12) as diffusers 0.14 writes it: sigma_t = eta * sqrt((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)); the stochastic
+        term (eta > 0) draws ONE batch-shaped normal tensor from `generator` per step (randn_tensor), or uses `variance_noise`"""
         t = int(timestep)
         a_t, a_p = float(self._a(t)), float(self._a(t - self.ratio))
         x, e = sample.float(), model_output.float()
         x0 = (x - (1 - a_t) ** 0.5 * e) / a_t ** 0.5
-        prev = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * e
+        var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+        std = float(eta) * max(var, 0.0) ** 0.5
+        prev = a_p ** 0.5 * x0 + max(1 - a_p - std * std, 0.0) ** 0.5 * e
+        if eta > 0:
+            if variance_noise is None:
+                gdev = generator.device if generator is not None else sample.device
+                variance_noise = torch.randn(sample.shape, generator=generator, device=gdev, dtype=sample.dtype).to(sample.device)
+            prev = prev + std * variance_noise.float()
         return SimpleNamespace(prev_sample=prev.to(sample.dtype))
 
 

@@ -31,12 +31,15 @@ class DDIM:
         self.ratio = 1000 // n
         self.timesteps = [int(i * self.ratio) + 1 for i in range(n)][::-1]
 
-    def step(self, eps, t, x):
+    def step(self, eps, t, x, eta=0.0, noise=None):
+        """DDIM eq. (12); eta > 0 adds sigma_t * noise with sigma_t = eta * sqrt((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev))"""
         tp = t - self.ratio
         a_t = self.ac[t]
         a_p = self.ac[tp] if tp >= 0 else self.final_ac
         x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
-        return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
+        std = eta * ((1 - a_p) / (1 - a_t) * (1 - a_t / a_p)) ** 0.5
+        out = a_p ** 0.5 * x0 + (1 - a_p - std ** 2) ** 0.5 * eps
+        return out + std * noise if eta > 0 else out
 
 
 class PNDM:

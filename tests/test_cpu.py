@@ -299,6 +299,32 @@ def test_shim_schedulers_match_oracle_on_cpu():
         assert torch.allclose(xs, xo, rtol=1e-5, atol=1e-5)
         assert s.init_noise_sigma == 1.0 and s.order == 1 and s.config.steps_offset == 1 and s.config.skip_prk_steps is True
         assert s.scale_model_input(x, 5) is x
+    # DDIM with eta > 0 (tryon_pipe.py:331-346 passes eta / generator through to scheduler.step): the stochastic term, drawn from the
+    # generator exactly once per step with the sample's shape, vs the oracle's eq. (12) with the same draws
+    s, o = L.DDIMScheduler(), P.make_scheduler(0)
+    s.set_timesteps(7); o.set_timesteps(7)
+    x = torch.randn((2, 4, 8, 6), generator=g)
+    xs, xo = x.clone(), x.clone()
+    gs, go = torch.Generator().manual_seed(11), torch.Generator().manual_seed(11)
+    for t in o.timesteps:
+        e = torch.randn((2, 4, 8, 6), generator=g)
+        xs = s.step(e, t, xs, eta=0.7, generator=gs).prev_sample
+        xo = o.step(e, t, xo, eta=0.7, noise=torch.randn((2, 4, 8, 6), generator=go))
+    assert torch.allclose(xs, xo, rtol=1e-5, atol=1e-5)
+
+
+def test_pipeline_generator_lists_draw_per_sample():
+    """diffusers randn_tensor semantics for a list of generators (tryon_pipe.py:443-455): sample i of every draw comes from generator i"""
+    import ladi_vton_amd as L
+    pipe = L.StableDiffusionTryOnePipeline.__new__(L.StableDiffusionTryOnePipeline)
+    gens = [torch.Generator().manual_seed(5 + i) for i in range(3)]
+    a = pipe._draw((3, 4, 2, 2), gens, torch.float32, torch.device("cpu"))
+    b = pipe._draw((3, 4, 2, 2), gens, torch.float32, torch.device("cpu"))
+    for i in range(3):
+        gi = torch.Generator().manual_seed(5 + i)
+        assert torch.equal(a[i], torch.randn((1, 4, 2, 2), generator=gi)[0]) and torch.equal(b[i], torch.randn((1, 4, 2, 2), generator=gi)[0])
+    with pytest.raises(ValueError):
+        pipe._draw((2, 4, 2, 2), gens, torch.float32, torch.device("cpu"))
 
 
 def test_pipeline_check_inputs_errors():
