@@ -4,6 +4,7 @@ Drop-in module shims + pipeline over libladi_native.so (hand-written HIP, see cs
 There is no CPU fallback: constructing any Native* module without a ROCm GPU raises NativeError.
 """
 from . import configs  # noqa: F401
+from . import dataset  # noqa: F401  (host-side VITON-HD / DressCode readers)
 from ._lib import NativeError  # noqa: F401
 from .modules import (NativeEMASC, NativeInversionAdapter, NativeUNet, NativeVAE, mask_features)  # noqa: F401
 from .pipeline import StableDiffusionTryOnePipeline  # noqa: F401

@@ -308,6 +308,50 @@ class LMSDiscreteScheduler(_SchedBase):
 _installed = False
 
 
+def _install_dataset_stubs(mod):
+    """stand-ins for the two imports of src/dataset/{vitonhd,dresscode}.py that are absent here: cv2 (only `dilate` is used) and
+    torchvision.transforms (Compose / ToTensor / Normalize).  scipy's grey dilation is the independent restatement of cv2.dilate."""
+    import numpy as np
+    from scipy import ndimage
+
+    def dilate(src, kernel, iterations=1):
+        out = np.asarray(src)
+        for _ in range(iterations):
+            out = ndimage.grey_dilation(out, footprint=np.asarray(kernel) != 0, mode="constant", cval=0)
+        return out
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToTensor:
+        def __call__(self, pic):
+            a = np.asarray(pic)
+            if a.ndim == 2:
+                a = a[:, :, None]
+            t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+            return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = mean, std
+
+        def __call__(self, t):
+            m = torch.tensor(self.mean, dtype=t.dtype).view(-1, 1, 1)
+            s = torch.tensor(self.std, dtype=t.dtype).view(-1, 1, 1)
+            return t.clone().sub_(m).div_(s)
+
+    mod("cv2", dilate=dilate)
+    tf = mod("torchvision.transforms.functional")
+    tr = mod("torchvision.transforms", Compose=Compose, ToTensor=ToTensor, Normalize=Normalize, functional=tf)
+    mod("torchvision", transforms=tr)
+
+
 def install():
     """put the stand-in `diffusers` package into sys.modules and the reference on sys.path (idempotent)"""
     global _installed
@@ -335,6 +379,7 @@ def install():
     mod("diffusers.pipelines.stable_diffusion", StableDiffusionPipelineOutput=StableDiffusionPipelineOutput)
     mod("diffusers.pipelines.stable_diffusion.pipeline_stable_diffusion_inpaint", prepare_mask_and_masked_image=prepare_mask_and_masked_image)
     mod("diffusers.schedulers", DDIMScheduler=DDIMScheduler, LMSDiscreteScheduler=LMSDiscreteScheduler, PNDMScheduler=PNDMScheduler)
+    _install_dataset_stubs(mod)
     if REF not in sys.path:
         sys.path.insert(0, REF)
     _installed = True

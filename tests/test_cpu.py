@@ -438,3 +438,42 @@ def test_sharded_run_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("OK %d" % r) in o, o
+
+
+def test_dataset_preprocessing_matches_real_reference_classes(tmp_path):
+    """ladi_vton_amd.dataset (host-side VITON-HD / DressCode readers: label-map algebra, PIL rasterisation, box dilation, pose heat-maps)
+    vs fixtures produced by the REAL src/dataset/vitonhd.py / dresscode.py classes on the same synthetic trees (oracle/make_golden.py:
+    make_dataset_golden).  Integer / byte outputs bit-exact; the fp32 maps to 1e-6."""
+    from oracle.make_golden import DATASET_KEYS
+    from tests import util_data as UD
+    from ladi_vton_amd.dataset import DressCodeDataset, VitonHDDataset, dilate_box
+    g = load_file(os.path.join(GOLD, "dataset_ref.safetensors"))
+    UD.make_vitonhd(str(tmp_path / "viton"), n=4)
+    UD.make_dresscode(str(tmp_path / "dc"), per_category=2)
+    keys = DATASET_KEYS + ("c_name", "im_name", "category")
+    sets = {"viton_unpaired": VitonHDDataset(str(tmp_path / "viton"), "test", order="unpaired", outputlist=keys, size=(128, 96)),
+            "dc_paired": DressCodeDataset(str(tmp_path / "dc"), "test", order="paired", outputlist=keys, size=(128, 96))}
+    for tag, ds in sets.items():
+        assert len(ds) == int(g["%s.len" % tag][0]) and len(ds) >= 4
+        for i in range(len(ds)):
+            it = ds[i]
+            assert bytes(g["%s.%d.names" % (tag, i)].tolist()).decode() == it["im_name"] + "|" + it["c_name"] + "|" + it["category"]
+            for k in ("inpaint_mask", "parse_mask_total"):
+                assert torch.equal(torch.as_tensor(it[k]).to(torch.uint8), g["%s.%d.%s" % (tag, i, k)]), (tag, i, k)
+            assert it["inpaint_mask"].shape == (1, 128, 96) and it["inpaint_mask"].dtype == torch.uint8
+            assert 0 < int(it["inpaint_mask"].sum()) < 128 * 96              # the synthetic person really has a garment region
+            for k in ("image", "cloth", "im_mask"):
+                assert torch.equal(it[k][:, ::2, ::2], g["%s.%d.%s" % (tag, i, k)]), (tag, i, k)
+            assert torch.allclose(it["pose_map"][:, ::4, ::4], g["%s.%d.pose_map" % (tag, i)], atol=1e-6, rtol=0)
+            assert torch.allclose(it["pose_map"].double().sum(dim=(1, 2)).float(), g["%s.%d.pose_map.sum" % (tag, i)], rtol=1e-6)
+            assert it["pose_map"].shape == (18, 128, 96) and float(it["pose_map"][17].abs().max()) == 0.0   # undetected joint
+    # the numpy box dilation == cv2.dilate(5x5, iterations=5) as restated by scipy's grey dilation
+    from scipy import ndimage
+    import numpy as np
+    m = (np.random.default_rng(0).random((40, 30)) > 0.97).astype(np.float32) * 255
+    ref = m
+    for _ in range(5):
+        ref = ndimage.grey_dilation(ref, footprint=np.ones((5, 5), bool), mode="constant", cval=0)
+    assert np.array_equal(dilate_box(m, 5, 5), ref)
+    with pytest.raises(ValueError):
+        VitonHDDataset(str(tmp_path / "viton"), "test", outputlist=("dense_uv",))
