@@ -1,24 +1,41 @@
+# Regenerates every round-2 artifact under profiles/ in ONE GPU call (run from the repo root on the GPU box):
+#   bash tools/make_profiles.sh            -> writes gpurun_out/r02_*; copy what is to be judged into profiles/
 set -u
 R=$PWD
-mkdir -p gpurun_out
-cp profiles/r01_igemm_tune_cache_B8.txt gpurun_out/tune.txt
-export LADI_TUNE_CACHE=$R/gpurun_out/tune.txt
-timeout 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-timeout 300 python bench.py --roofline-only --no-cpu-baseline > gpurun_out/bench_roofline_only.json 2>/dev/null
+O=$R/gpurun_out
+mkdir -p $O
+DIG=$(cat ladi_vton_amd/csrc/_obj/stamp)
+# 1. tile selections for the BASELINE batch sizes (the table shipped as ladi_vton_amd/tune_gfx950.txt)
+export LADI_TUNE_NO_SHIPPED=1
+export LADI_TUNE_CACHE=$O/r02_tune.txt
+rm -f $LADI_TUNE_CACHE
+timeout 900 python bench.py --cpu-runs 3 --steps 10 --warmup 3 > $O/r02_bench_default.json 2> $O/r02_bench_default.err
+timeout 300 python bench.py --config 2 --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > $O/r02_bench_config2.json 2>/dev/null
+timeout 300 python bench.py --scheduler ddim --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $O/r02_bench_ddim.json 2>/dev/null
+timeout 400 python bench.py --config 4 --no-cpu-baseline --no-roofline --steps 1 --warmup 1 > $O/r02_bench_config4.json 2>/dev/null
+timeout 300 python bench.py --roofline-only --no-cpu-baseline > $O/r02_bench_roofline_only.json 2>/dev/null
+# 2. kernel traces (tuned selections preloaded: no tuning launches in the traces)
 cd /tmp; export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt -- python $R/bench.py --roofline-only --no-cpu-baseline > /dev/null 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_f -- python $R/bench.py --roofline-only --no-cpu-baseline > /dev/null 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_w -- python $R/bench.py --roofline-only --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -- python $R/bench.py --roofline-only --no-cpu-baseline > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/ktb -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 1 --warmup 1 > /dev/null 2>&1
+# 3. PMC passes, each in its own run (FETCH_SIZE and WRITE_SIZE cannot share a pass)
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_f -- python $R/bench.py --roofline-only --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_w -- python $R/bench.py --roofline-only --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_m -- python $R/bench.py --roofline-only --no-cpu-baseline > /dev/null 2>&1
+# VAE / EMASC stages alone (counter collection segfaults on the hipGraph-replaying full bench): time + HBM bytes per kernel
+timeout 300 python $R/tools/bench_vae.py > $O/r02_vae_stages.txt 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/ktv -- python $R/tools/bench_vae.py --iters 1 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fv -- python $R/tools/bench_vae.py --iters 1 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_wv -- python $R/tools/bench_vae.py --iters 1 > /dev/null 2>&1
 cd $R
-python tools/rocpd_stats.py $(find gpurun_out/kt -name "*.db" | head -1) gpurun_out/kstats.txt > /dev/null
-python tools/rocpd_pmc.py $(find gpurun_out/pmc_f -name "*.db" | head -1) gpurun_out/pmc_fetch.txt > /dev/null
-python tools/rocpd_pmc.py $(find gpurun_out/pmc_w -name "*.db" | head -1) gpurun_out/pmc_write.txt > /dev/null
-find gpurun_out -name "*.db" -delete
-rm -rf gpurun_out/kt gpurun_out/pmc_f gpurun_out/pmc_w
-head -c 600 gpurun_out/bench_default.json; echo; tail -3 gpurun_out/bench_default.err; head -8 gpurun_out/kstats.txt; head -5 gpurun_out/pmc_fetch.txt
-# extra bench points quoted in BASELINE.md §4 / README.md
-timeout 300 python bench.py --scheduler ddim --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/bench_ddim.json
-unset LADI_TUNE_CACHE
-timeout 500 python bench.py --batch 32 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/bench_b32.json
-timeout 500 python bench.py --height 1024 --width 768 --batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/bench_1024x768_b4.json
-for f in bench_ddim bench_b32 bench_1024x768_b4; do head -c 150 gpurun_out/$f.json; echo; done
+python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) $O/r02_unet_forward_kernel_stats.txt > /dev/null
+python tools/rocpd_stats.py $(find $O/ktb -name "*.db" | head -1) $O/r02_bench_kernel_stats.txt > /dev/null
+python tools/rocpd_pmc.py $(find $O/pmc_f -name "*.db" | head -1) $O/r02_pmc_fetch_size.txt --digest $DIG > /dev/null
+python tools/rocpd_pmc.py $(find $O/pmc_w -name "*.db" | head -1) $O/r02_pmc_write_size.txt --digest $DIG > /dev/null
+python tools/rocpd_pmc.py $(find $O/pmc_m -name "*.db" | head -1) $O/r02_pmc_mfma_busy.txt --digest $DIG > /dev/null
+python tools/rocpd_stats.py $(find $O/ktv -name "*.db" | head -1) $O/r02_vae_kernel_stats.txt > /dev/null
+python tools/rocpd_pmc.py $(find $O/pmc_fv -name "*.db" | head -1) $O/r02_vae_pmc_fetch_size.txt --digest $DIG > /dev/null
+python tools/rocpd_pmc.py $(find $O/pmc_wv -name "*.db" | head -1) $O/r02_vae_pmc_write_size.txt --digest $DIG > /dev/null
+rm -rf $O/kt $O/ktb $O/pmc_f $O/pmc_w $O/pmc_m $O/ktv $O/pmc_fv $O/pmc_wv
+head -c 400 $O/r02_bench_default.json; echo; tail -2 $O/r02_bench_default.err
+head -12 $O/r02_unet_forward_kernel_stats.txt; head -8 $O/r02_pmc_mfma_busy.txt; wc -l $O/r02_tune.txt
