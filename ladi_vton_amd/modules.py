@@ -229,13 +229,14 @@ class NativeVAE(_Base):
         arr = None
         keep = []
         if intermediate_features:
-            # Decoder.forward (vae.py:188-205) zips the REVERSED list with the up blocks and adds layer 1 after conv_norm_out: the shapes
-            # only line up when int_layers is a contiguous run ending at 5 ([1..5], [2..5], [3..5], [4, 5], [5]); anything else fails in
-            # the reference with a tensor-shape error
+            # Decoder.forward (vae.py:188-205) zips the REVERSED list with the four up blocks (a list shorter than four silently SKIPS the
+            # remaining up blocks, which the released channel widths then reject at conv_norm_out) and adds layer 1 after conv_norm_out:
+            # the only selections whose shapes line up are [1, 2, 3, 4, 5] and [2, 3, 4, 5]
             layers = list(int_layers or [])
-            if not layers or layers != list(range(layers[0], 6)) or layers[0] < 1 or len(intermediate_features) != len(layers):
-                raise ValueError("int_layers must be a contiguous run ending at 5 with one feature per layer (got %r with %d features): "
-                                 "the reference's Decoder.forward cannot add any other selection" % (int_layers, len(intermediate_features)))
+            if layers not in ([1, 2, 3, 4, 5], [2, 3, 4, 5]) or len(intermediate_features) != len(layers):
+                raise ValueError("int_layers must be [1, 2, 3, 4, 5] or [2, 3, 4, 5] with one feature per layer (got %r with %d features): "
+                                 "the reference's Decoder.forward cannot run any other selection on the released architecture"
+                                 % (int_layers, len(intermediate_features)))
             keep = [_nhwc_buffer(f) for f in intermediate_features]
             slots = [None] * 5
             for layer, k in zip(layers, keep):
