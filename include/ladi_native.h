@@ -250,6 +250,9 @@ typedef struct {
     const void* bias; int bias_per_pixel; const float* rowadd; const int* rowadd_idx; int rowadd_stride; int act; float out_scale;
     const void* res0; const void* res1; int ldr0, ldr1; const void* mask; void* out; int ldo; int out_f32;
     float* stats; int stats_groups; int splitk, tile_map /* both ignored: set by the launcher */;
+    const void* ln_gamma; const void* ln_beta; float ln_eps; int ln_pad_; void* ln_scratch;
+    /* optional LayerNorm of the pixel operand (single source, 1x1): fused into the X-stationary linear kernel where the tuner finds that
+       faster, else run as its own kernel into ln_scratch ([P][C0] fp16, caller-provided; null = only the fused form is admissible) */
 } ladi_igemm_desc;
 int ladi_op_igemm(const ladi_igemm_desc* d, int batch, int tile_cfg, void* stream);
 int ladi_op_group_norm(const void* src0, int C0, const void* src1, int C1, int n, int HW, int groups, const void* gamma,

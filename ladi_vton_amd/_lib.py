@@ -76,7 +76,8 @@ class IGemmDesc(Structure):
                 ("bias", c_void_p), ("bias_per_pixel", c_int), ("rowadd", c_void_p), ("rowadd_idx", c_void_p),
                 ("rowadd_stride", c_int), ("act", c_int), ("out_scale", c_float),
                 ("res0", c_void_p), ("res1", c_void_p), ("ldr0", c_int), ("ldr1", c_int), ("mask", c_void_p),
-                ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("stats", c_void_p), ("stats_groups", c_int), ("splitk", c_int), ("tile_map", c_int)]
+                ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("stats", c_void_p), ("stats_groups", c_int), ("splitk", c_int), ("tile_map", c_int),
+                ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("ln_pad_", c_int), ("ln_scratch", c_void_p)]
 
 
 # every symbol include/ladi_native.h declares: name -> (restype, argtypes)

@@ -104,4 +104,10 @@ struct IGemmArgs {
     int stats_groups;    // unused
     int splitk;          // set by the launcher: > 1 = grid.z slices K, fp32 partials to `out` (+ z*bs_out), reduced by a 2nd kernel
     int tile_map;        // set by the launcher: 0 plain, 1 pixel tiles split over XCDs, 2 channel tiles split over XCDs
+    // optional LayerNorm of the pixel operand: x <- (x - mean) * rstd * gamma + beta over the C0 channels of every pixel, rounded to
+    // fp16 (null = none).  The X-stationary linear kernel fuses it into its prologue (the wave holds whole rows in registers); every
+    // other configuration runs the stand-alone LayerNorm kernel into ln_scratch ([P][C0] fp16) first -- the tuner times both forms
+    const h16* ln_gamma; const h16* ln_beta;
+    float ln_eps; int ln_pad_;
+    h16* ln_scratch;
 };

@@ -440,7 +440,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     //      capture, every admissible configuration is timed with HIP events on the launch stream and the fastest is cached.
     //      Re-running a launch is idempotent (outputs never alias inputs in this library).
     // flags also carry the epilogue features that decide which kernels are admissible (residuals, fused statistics, other)
-    const int epi = ((a.res0 || a.res1) ? 2 : 0) | (a.stats ? 8 : 0) |
+    const int epi = (a.ln_gamma ? 128 : 0) | ((a.res0 || a.res1) ? 2 : 0) | (a.stats ? 8 : 0) |
                     ((a.rowadd || a.mask || a.bias_per_pixel || a.out_f32 || a.out_scale != 1.f || (a.act != LADI_ACT_NONE && !geglu)) ? 64 : 0);
     TuneKey key{a.P, a.Q, a.K, a.C0, a.C1, a.Wo, (a.ksize << 8) | (a.stride << 4) | (a.ups << 2) | (geglu ? 1 : 0) | epi, batch};
     if (cfg == 0 && g_autotune) {
@@ -458,6 +458,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                     std::vector<std::pair<float, int>> cand;     // (ms per launch incl. penalty, cfg)
                                         for (int c = 1; c <= NCFG; ++c) {
                         if (kCfg[c].blocks_per_cu < 2) continue;                       // 1-block/CU shapes never won
+                        if (a.ln_gamma && kCfg[c].base != 23 && !a.ln_scratch) continue;  // no scratch: only the fused form
                         float penalty_ms = 0.f;
                         if (kCfg[c].base == 23) {
                             IGemmArgs t = a; t.stats = nullptr;
@@ -528,6 +529,12 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         }
     }
     if (cfg < 1 || cfg > NCFG) return -7;
+    if (a.ln_gamma && kCfg[cfg].base != 23) {   // LayerNorm as its own kernel into the caller's scratch (timed by the tuner as part of cfg)
+        if (!a.ln_scratch || a.C1 || a.src1 || a.ksize != 1 || batch != 1) return -15;
+        const int lrc = ladi_launch_layernorm(a.src0, a.ld0, a.ln_gamma, a.ln_beta, a.ln_eps, a.P, a.C0, a.ln_scratch, a.C0, st);
+        if (lrc != 0) return -15;
+        a.src0 = a.ln_scratch; a.ld0 = a.C0; a.ln_gamma = nullptr; a.ln_beta = nullptr;
+    }
     if (kCfg[cfg].base == 23) {   // X-stationary linear kernel: no fused statistics (the consumer falls back to ladi_launch_gn_partial)
         a.stats = nullptr;
         if (!ladi_linear_xs_eligible(a, batch, kCfg[cfg].tp, kCfg[cfg].bq)) return -14;

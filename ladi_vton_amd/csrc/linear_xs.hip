@@ -46,8 +46,10 @@ __device__ __forceinline__ void wait_vm_n(int n) {
 #undef XS_CASE
 
 // KH = K / 320, PB = 32-pixel blocks per wave, MODE 0: bias | 1: bias + residual (PB == 1) | 2: GEGLU (PB == 1; 32-row blocks of W
-// alternate u | g).  grid = (P / (128*PB), channel slices); block = 4 waves.
-template <int KH, int PB, int MODE>
+// alternate u | g), LN: LayerNorm of the pixel panel in the prologue (a compile-time variant: a run-time branch around the rewrite
+// of the 160-VGPR panel makes the compiler keep both versions live and spill ~250 VGPRs).
+// grid = (P / (128*PB), channel slices); block = 4 waves.
+template <int KH, int PB, int MODE, bool LN>
 __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, int qb_per_slice) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* ring = smem_raw;
@@ -124,6 +126,58 @@ __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, in
     issue_w(0); m_cur = vm_issued;
     if (nstage > 1) { issue_w(1); m_next = vm_issued; }
     if (MODE == 1) { issue_res(ob0); mr_cur = vm_issued; }
+    // ---- optional fused LayerNorm (a.ln_gamma): the lane pair (l31, hh = 0 / 1) holds one whole pixel row, so the statistics are two
+    //      register passes and one cross-half shuffle each; same arithmetic and rounding point (fp16 result) as layernorm_kernel
+    if constexpr (LN) {
+        // pin(): an ordered no-op on one 4-VGPR fragment.  The three passes are fully unrolled over a 160-VGPR panel; left alone the
+        // scheduler hoists every fp16 -> fp32 conversion to the top (320+ live floats, 500+ spilled VGPRs).  A pin before and after
+        // each fragment's arithmetic chains the fragments one after another, so only one fragment's floats are live at a time.
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        auto pin = [](h16x8& v) {
+            i32x4 t = __builtin_bit_cast(i32x4, v);
+            asm volatile("" : "+v"(t));
+            v = __builtin_bit_cast(h16x8, t);
+        };
+        const float invK = 1.f / (float)K;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            float s = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                pin(xf[pb][ks]);
+                float t = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t += (float)xf[pb][ks][e];
+                s += t;
+                asm volatile("" : "+v"(s));
+            }
+            s += __shfl_xor(s, 32);
+            const float mean = s * invK;
+            float q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                pin(xf[pb][ks]);
+                float t = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)xf[pb][ks][e] - mean; t += d * d; }
+                q += t;
+                asm volatile("" : "+v"(q));
+            }
+            q += __shfl_xor(q, 32);
+            const float rstd = rsqrtf(q * invK + a.ln_eps);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                pin(xf[pb][ks]);
+                const h16x8 g = *reinterpret_cast<const h16x8*>(a.ln_gamma + ks * 16 + hh * 8);
+                const h16x8 b = *reinterpret_cast<const h16x8*>(a.ln_beta + ks * 16 + hh * 8);
+                h16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)xf[pb][ks][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+                xf[pb][ks] = o;
+                pin(xf[pb][ks]);
+            }
+        }
+    }
     // ---- bias of this slice -> LDS, last in the prologue (its wait drains everything above, which stage 0 needs anyway)
     for (int i = tid; i < qb_per_slice * 32; i += 256) bias_s[i] = a.bias ? a.bias[qb0 * 32 + i] : (h16)0.f;
 
@@ -238,12 +292,12 @@ __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, in
     }
 }
 
-template <int KH, int PB, int MODE>
-int launch_xs(const IGemmArgs& a, int qs, hipStream_t st) {
+template <int KH, int PB, int MODE, bool LN>
+int launch_xs_ln(const IGemmArgs& a, int qs, hipStream_t st) {
     const int qb_per_slice = (a.Q / 32) / qs;
     const int smem = XS_NST * XS_STAGE + 4 * (MODE == 1 ? 2 * XS_RPATCH : XS_PATCH) + qb_per_slice * 32 * 2;
     if (smem > XS_SMEM_MAX) return -10;
-    auto kfn = linear_xs_kernel<KH, PB, MODE>;
+    auto kfn = linear_xs_kernel<KH, PB, MODE, LN>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, XS_SMEM_MAX) != hipSuccess) return -10;
@@ -252,6 +306,11 @@ int launch_xs(const IGemmArgs& a, int qs, hipStream_t st) {
     dim3 grid((unsigned)(a.P / (128 * PB)), (unsigned)qs);
     hipLaunchKernelGGL(kfn, grid, dim3(256), smem, st, a, qb_per_slice);
     return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+template <int KH, int PB, int MODE>
+int launch_xs(const IGemmArgs& a, int qs, hipStream_t st) {
+    return a.ln_gamma ? launch_xs_ln<KH, PB, MODE, true>(a, qs, st) : launch_xs_ln<KH, PB, MODE, false>(a, qs, st);
 }
 
 }  // namespace

@@ -88,6 +88,7 @@ struct ConvOpt {
     int out_ld = 0;          // 0 -> cout (GEGLU: cout/2)
     int cfg = 0;             // igemm tile config override
     bool stats = false;      // also produce per-channel partial statistics of the output (for a consuming GroupNorm)
+    const DNorm* ln = nullptr; float ln_eps = 1e-5f;   // LayerNorm applied to the input first: fused into the kernel when it can be, else a launch
 };
 
 DConv load_conv(DevPool& pool, const WeightStore& ws, const std::string& prefix, int cin_expected = -1);      // 4-D or 2-D weight

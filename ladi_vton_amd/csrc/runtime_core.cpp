@@ -228,6 +228,13 @@ Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& 
     if (o.res1) { a.res1 = o.res1->p; a.ldr1 = o.res1->ld; }
     a.mask = o.mask;
     a.out_f32 = 0;
+    if (o.ln) {
+        if (x2 || o.ln->c != C0) throw std::runtime_error("conv2d: LayerNorm input must be a single source of matching width");
+        a.ln_gamma = o.ln->g; a.ln_beta = o.ln->b; a.ln_eps = o.ln_eps;
+        // fused into the X-stationary kernel or run as its own kernel into this scratch: the tuner decides per shape, so the
+        // scratch is reserved unconditionally (the planning pass and the real pass allocate identically)
+        a.ln_scratch = c.new_act(x.n, x.h, x.w, C0).p;
+    }
     launch_conv_into(c, a, out, o.cfg);
     return out;
 }

@@ -194,19 +194,18 @@ struct Fwd {
         Act tok = g; tok.h = T; tok.w = 1;  // tokens view [n][T][C]
         ConvOpt op;
         Act t0 = conv2d(c, b.proj_in, tok, nullptr, op);
-        Act a1 = layer_norm(c, b.ln1, t0, 1e-5f);
-        Act qkv = conv2d(c, b.qkv, a1, nullptr, op);
+        ConvOpt oq; oq.ln = &b.ln1;                  // LayerNorm fused into the K = 320 / 640 projections (X-stationary kernel), else a launch
+        Act qkv = conv2d(c, b.qkv, t0, nullptr, oq);
         Act o1 = attn(qkv.p, 3 * C, (long long)T * 3 * C, qkv.p + C, qkv.p + 2 * C, 3 * C, (long long)T * 3 * C, n, T, T, b.heads);
         ConvOpt or1; or1.res0 = &t0;
         Act t1 = conv2d(c, b.o1, o1, nullptr, or1);
-        Act a2 = layer_norm(c, b.ln2, t1, 1e-5f);
-        Act q2 = conv2d(c, b.q2, a2, nullptr, op);
+        ConvOpt oq2; oq2.ln = &b.ln2;
+        Act q2 = conv2d(c, b.q2, t1, nullptr, oq2);
         Act o2 = attn(q2.p, C, (long long)T * C, b.kv_cache, b.kv_cache + C, 2 * C, (long long)u.ctx_L * 2 * C, n, T, u.ctx_L, b.heads);
         ConvOpt or2; or2.res0 = &t1;
         Act t2 = conv2d(c, b.o2, o2, nullptr, or2);
-        Act a3 = layer_norm(c, b.ln3, t2, 1e-5f);
-        ConvOpt og; og.act = LADI_ACT_GEGLU;
-        Act gg = conv2d(c, b.ff1, a3, nullptr, og);
+        ConvOpt og; og.act = LADI_ACT_GEGLU; og.ln = &b.ln3;
+        Act gg = conv2d(c, b.ff1, t2, nullptr, og);
         ConvOpt or3; or3.res0 = &t2;
         Act t3 = conv2d(c, b.ff2, gg, nullptr, or3);
         Act xin = x; xin.h = T; xin.w = 1;

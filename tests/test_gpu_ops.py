@@ -597,3 +597,49 @@ def test_grid_sample_border_matches_torch(lib):
     assert (got.cpu() - ref).abs().max() <= 2e-5, (got.cpu() - ref).abs().max()
     got16 = L.grid_sample_border(x.half().to(U.dev()), grid.to(U.dev()))
     assert got16.dtype == torch.float16 and (got16.float().cpu() - F.grid_sample(x.half().float(), grid, padding_mode="border", align_corners=False)).abs().max() <= 2e-3
+
+
+@pytest.mark.parametrize("C,Q,hw,act", [(320, 960, (32, 16), "none"), (640, 640, (16, 16), "none"), (320, 2560, (16, 24), "geglu"),
+                                        (640, 5120, (8, 16), "geglu")])
+def test_linear_with_fused_layernorm(C, Q, hw, act):
+    """LayerNorm fused into the X-stationary linear kernel's prologue (BasicTransformerBlock norm1 -> to_q/k/v, norm2 -> attn2.to_q,
+    norm3 -> GEGLU; K = 320 / 640): same arithmetic and fp16 rounding point as the stand-alone LayerNorm + linear"""
+    x = _rand((1, C) + hw, 110) * 2.0 + 0.3
+    gamma, beta = 1.0 + 0.1 * _rand((C,), 111), 0.1 * _rand((C,), 112)
+    w, b = _rand((Q, C), 113, 1 / math.sqrt(C)), _rand((Q,), 114, 0.1)
+    t = x[0].reshape(C, -1).t()
+    xn = F.layer_norm(t, (C,), gamma, beta, 1e-5).half().float()
+    if act == "geglu":
+        u, g = F.linear(xn, w, b).chunk(2, -1)
+        ref = u * F.gelu(g)
+        half = Q // 2
+        wi, bi = torch.zeros_like(w), torch.zeros_like(b)
+        for j in range(half):
+            blk, i = divmod(j, 32)
+            wi[blk * 64 + i], wi[blk * 64 + 32 + i] = w[j], w[half + j]
+            bi[blk * 64 + i], bi[blk * 64 + 32 + i] = b[j], b[half + j]
+        y = U.igemm(U.nhwc16(x), wi.half().contiguous().to(U.dev()), Q, ksize=1, bias=bi, act="geglu", ln=(gamma, beta, 1e-5))
+        got = y.float().cpu().reshape(-1, half)
+    else:
+        ref = F.linear(xn, w, b)
+        y = U.igemm(U.nhwc16(x), w.half().contiguous().to(U.dev()), Q, ksize=1, bias=b, ln=(gamma, beta, 1e-5))
+        got = y.float().cpu().reshape(-1, Q)
+    assert U.rel_l2(got, ref) < TOL, U.rel_l2(got, ref)
+
+
+@pytest.mark.parametrize("C,Q,cfg", [(128, 128, 0), (320, 960, 7), (320, 960, 0), (1280, 1280, 0)])
+def test_layernorm_through_the_scratch(C, Q, cfg):
+    """shapes / configurations the X-stationary kernel does not take: the launcher runs the stand-alone LayerNorm kernel into the
+    caller's scratch and feeds the GEMM from there (cfg 0: the tuner times the fused and the two-kernel form and keeps the faster)"""
+    x, w, b = _rand((1, C, 16, 16), 115) + 0.2, _rand((Q, C), 116, 1 / math.sqrt(C)), _rand((Q,), 117, 0.1)
+    gamma, beta = 1.0 + 0.1 * _rand((C,), 118), 0.1 * _rand((C,), 119)
+    ref = F.linear(F.layer_norm(x[0].reshape(C, -1).t(), (C,), gamma, beta, 1e-5).half().float(), w, b)
+    y = U.igemm(U.nhwc16(x), w.half().contiguous().to(U.dev()), Q, ksize=1, bias=b, cfg=cfg, ln=(gamma, beta, 1e-5, True))
+    assert U.rel_l2(y.float().cpu().reshape(-1, Q), ref) < TOL
+
+
+def test_layernorm_without_scratch_needs_a_fusable_shape():
+    """no scratch: only the fused form is admissible, anything else is an error (never a silently skipped LayerNorm)"""
+    x, w = _rand((1, 128, 16, 16), 115), _rand((128, 128), 116, 0.1)
+    with pytest.raises(AssertionError):
+        U.igemm(U.nhwc16(x), w.half().contiguous().to(U.dev()), 128, ksize=1, ln=(torch.ones(128), torch.zeros(128), 1e-5))

@@ -38,7 +38,7 @@ def pack_conv_weight_cat(w, c0, c1):
 
 
 def igemm(x, w_packed, cout, ksize=3, stride=1, pad=None, ups=0, x2=None, bias=None, rowadd=None, act="none", res0=None, res1=None,
-          mask=None, out_f32=False, cfg=0, out_ld=None):
+          mask=None, out_f32=False, cfg=0, out_ld=None, ln=None):
     """x, x2: NHWC fp16 gpu tensors [N,H,W,C]; returns NHWC output [N,Ho,Wo,ldo]"""
     lib = _lib.load()
     N, H, W, C0 = x.shape
@@ -67,6 +67,14 @@ def igemm(x, w_packed, cout, ksize=3, stride=1, pad=None, ups=0, x2=None, bias=N
         d.res1, d.ldr1 = res1.data_ptr(), res1.shape[3]
     if mask is not None:
         d.mask = mask.data_ptr()
+    if ln is not None:       # (gamma, beta, eps[, with_scratch]): LayerNorm of the pixel operand (fused, or via the scratch)
+        gm, bt = ln[0].half().to(x.device), ln[1].half().to(x.device)
+        keep += [gm, bt]
+        d.ln_gamma, d.ln_beta, d.ln_eps = gm.data_ptr(), bt.data_ptr(), float(ln[2])
+        if len(ln) > 3 and ln[3]:
+            scr = torch.empty((x.shape[0] * x.shape[1] * x.shape[2], x.shape[3]), dtype=torch.float16, device=x.device)
+            keep.append(scr)
+            d.ln_scratch = scr.data_ptr()
     d.out, d.ldo, d.out_f32 = out.data_ptr(), ldo, int(out_f32)
     rc = lib.ladi_op_igemm(ctypes.byref(d), 1, cfg, stream_ptr())
     assert rc == 0, "igemm rc=%d %s" % (rc, _lib.last_error())
