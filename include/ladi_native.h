@@ -179,11 +179,15 @@ int ladi_tps_forward(ladi_tps* t, const void* input_a_dev, const void* input_b_d
                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * Scheduler — replaces diffusers DDIMScheduler / PNDMScheduler (skip_prk_steps) set_timesteps + step
- * (tryon_pipe.py:650-651,740).  kind: 0 = DDIM, 1 = PNDM.
+ * Scheduler — replaces diffusers DDIMScheduler / PNDMScheduler (skip_prk_steps) / LMSDiscreteScheduler set_timesteps +
+ * scale_model_input + step (tryon_pipe.py:62,424,650-651,722,740).  kind: 0 = DDIM, 1 = PNDM, 2 = LMSDiscrete.
  * ------------------------------------------------------------------------------------------------------------- */
 /* host helper: writes the N (DDIM) or N+1 (PNDM) timesteps; returns their count, or negative on error */
 int ladi_sched_timesteps(int kind, int num_inference_steps, int* timesteps_out, int cap);
+/* host helper, LMSDiscrete (order 4): timesteps_out[N] (fractional, float64 as diffusers holds them), sigmas_out[N + 1] (trailing 0;
+ * init_noise_sigma = sigmas_out[0]), coeffs_out[N][4] = linear-multistep weights of evaluation i over its derivatives
+ * [d_i, d_{i-1}, d_{i-2}, d_{i-3}] (zero beyond the order min(i + 1, 4)).  alphas_cumprod_host null = default.  Any output may be null. */
+int ladi_sched_lms(int num_inference_steps, const float* alphas_cumprod_host, double* timesteps_out, float* sigmas_out, float* coeffs_out);
 /* host helper: default alphas_cumprod (scaled_linear 0.00085..0.012, 1000 steps), out[1000] */
 int ladi_sched_alphas_cumprod(float* out);
 
@@ -206,7 +210,7 @@ typedef struct {
     const float* noise_masked_dev;
     int num_inference_steps;
     float guidance_scale;
-    int scheduler;                     /* 0 DDIM, 1 PNDM */
+    int scheduler;                     /* 0 DDIM, 1 PNDM, 2 LMSDiscrete */
     int cloth_zero_from_eval;          /* first evaluation index i that sees zero cloth latents: the smallest i with
                                         * i >= num_inference_steps - (1 - cloth_cond_rate) * num_inference_steps, evaluated by the CALLER in
                                         * float64 exactly like tryon_pipe.py:654,718 (a float32 rate crossing the ABI shifts the cut-off by

@@ -119,6 +119,7 @@ SIGNATURES = {
     "ladi_text_encoder_destroy": (None, [_P]),
     "ladi_text_encoder_forward": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P, _P, _P]),
     "ladi_sched_timesteps": (c_int, [c_int, c_int, POINTER(c_int), c_int]),
+    "ladi_sched_lms": (c_int, [c_int, _P, _P, _P, _P]),
     "ladi_sched_alphas_cumprod": (c_int, [POINTER(c_float)]),
     "ladi_tryon_create": (_P, [_P, _P, _P]),
     "ladi_tryon_destroy": (None, [_P]),

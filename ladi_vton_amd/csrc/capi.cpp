@@ -417,11 +417,25 @@ int ladi_sched_timesteps(int kind, int steps, int* out, int cap) {
     return guarded("ladi_sched_timesteps", [&]() {
         if (steps < 2 || steps > 1000) throw std::runtime_error("num_inference_steps out of range");
         std::vector<float> ac; default_alphas_cumprod(ac);
-        std::vector<int> ts; std::vector<StepTable> tb;
+        if (kind == 2) throw std::runtime_error("LMSDiscrete timesteps are fractional: use ladi_sched_lms");
+        std::vector<double> ts; std::vector<StepTable> tb;
         build_step_table(kind, steps, ac.data(), 1 << 30, ts, tb);
         if ((int)ts.size() > cap) throw std::runtime_error("timesteps buffer too small");
-        for (size_t i = 0; i < ts.size(); ++i) out[i] = ts[i];
+        for (size_t i = 0; i < ts.size(); ++i) out[i] = (int)ts[i];
         return (int)ts.size();
+    });
+}
+int ladi_sched_lms(int steps, const float* ac_host, double* timesteps_out, float* sigmas_out, float* coeffs_out) {
+    return guarded("ladi_sched_lms", [&]() {
+        if (steps < 2 || steps > 1000) throw std::runtime_error("num_inference_steps out of range");
+        std::vector<float> ac;
+        if (ac_host) ac.assign(ac_host, ac_host + 1000); else default_alphas_cumprod(ac);
+        std::vector<double> ts; std::vector<StepTable> tb; SchedInfo info;
+        build_step_table(2, steps, ac.data(), 1 << 30, ts, tb, &info);
+        if (timesteps_out) std::memcpy(timesteps_out, ts.data(), ts.size() * sizeof(double));
+        if (sigmas_out) std::memcpy(sigmas_out, info.sigmas.data(), info.sigmas.size() * sizeof(float));
+        if (coeffs_out) std::memcpy(coeffs_out, info.lms_coeffs.data(), info.lms_coeffs.size() * sizeof(float));
+        return steps;
     });
 }
 int ladi_sched_alphas_cumprod(float* out) {
@@ -581,7 +595,7 @@ int ladi_op_posterior_sample(const void* moments, int ldm, const float* noise, i
 int ladi_op_assemble_input(void* unet_in, int ld, int B, int hw, int cfg, const float* latents, const void* mask_lat, const float* masked_lat,
                            const void* pose, int pose_ch, const float* cloth_lat, void* stream) {
     return ladi_launch_assemble_static((h16*)unet_in, ld, B, hw, cfg, latents, (const h16*)mask_lat, masked_lat, (const h16*)pose, pose_ch,
-                                       cloth_lat, cloth_lat ? 1 : 0, S(stream));
+                                       cloth_lat, cloth_lat ? 1 : 0, 1.0f, S(stream));
 }
 int ladi_op_sched_run(int kind, int steps, const float* ac_host, const void* eps_seq, int evals, int B, int hw, int cfg, float guidance,
                       float* latents, void* stream) {
@@ -589,7 +603,7 @@ int ladi_op_sched_run(int kind, int steps, const float* ac_host, const void* eps
         hipStream_t st = S(stream);
         std::vector<float> ac;
         if (ac_host) ac.assign(ac_host, ac_host + 1000); else default_alphas_cumprod(ac);
-        std::vector<int> ts; std::vector<StepTable> tb;
+        std::vector<double> ts; std::vector<StepTable> tb;
         build_step_table(kind, steps, ac.data(), 1 << 30, ts, tb);
         if (evals > (int)tb.size()) throw std::runtime_error("evals exceeds scheduler length");
         char* buf = nullptr;

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const StepArgs a) {
         if (a.trace_lat) reinterpret_cast<float4*>(a.trace_lat)[(size_t)step * total + idx] = xn;
     }
     if (a.unet_in) {
-        h16x4 o; o[0] = (h16)xn.x; o[1] = (h16)xn.y; o[2] = (h16)xn.z; o[3] = (h16)xn.w;
+        const float is = T.in_scale_next;
+        h16x4 o; o[0] = (h16)(xn.x * is); o[1] = (h16)(xn.y * is); o[2] = (h16)(xn.z * is); o[3] = (h16)(xn.w * is);
         *reinterpret_cast<h16x4*>(a.unet_in + row_u * a.ld_in) = o;
         if (a.cfg) *reinterpret_cast<h16x4*>(a.unet_in + row_c * a.ld_in) = o;
         if (T.zero_cloth_next) {
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void assemble_static_kernel(h16* __restrict__ 
                                                               const h16* __restrict__ mask_lat,
                                                               const float* __restrict__ masked_lat,
                                                               const h16* __restrict__ pose, int pose_ch,
-                                                              const float* __restrict__ cloth_lat, int has_cloth) {
+                                                              const float* __restrict__ cloth_lat, int has_cloth, float lat_scale) {
     const int rows = (cfg ? 2 : 1) * B * hw;
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void assemble_static_kernel(h16* __restrict__ 
     const int src = cfg ? (row % total) : row;
     h16* o = unet_in + (size_t)row * ld_in;
     int c = 0;
-    for (int i = 0; i < 4; ++i) o[c++] = (h16)latents[(size_t)src * 4 + i];
+    for (int i = 0; i < 4; ++i) o[c++] = (h16)(latents[(size_t)src * 4 + i] * lat_scale);   // scale_model_input of evaluation 0
     o[c++] = mask_lat[src];
     for (int i = 0; i < 4; ++i) o[c++] = (h16)masked_lat[(size_t)src * 4 + i];
     for (int i = 0; i < pose_ch; ++i) o[c++] = cond ? pose[(size_t)src * pose_ch + i] : (h16)0.f;
@@ -369,11 +370,11 @@ int ladi_launch_sched_step(const StepArgs& a, hipStream_t st) {
 
 int ladi_launch_assemble_static(h16* unet_in, int ld_in, int B, int hw, int cfg, const float* latents, const h16* mask_lat,
                                 const float* masked_lat, const h16* pose, int pose_ch, const float* cloth_lat, int has_cloth,
-                                hipStream_t st) {
+                                float lat_scale, hipStream_t st) {
     const int rows = (cfg ? 2 : 1) * B * hw;
     if (9 + pose_ch + (has_cloth ? 4 : 0) > ld_in) return -1;
     hipLaunchKernelGGL(assemble_static_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, unet_in, ld_in, B, hw, cfg, latents,
-                       mask_lat, masked_lat, pose, pose_ch, cloth_lat, has_cloth);
+                       mask_lat, masked_lat, pose, pose_ch, cloth_lat, has_cloth, lat_scale);
     return ok();
 }
 

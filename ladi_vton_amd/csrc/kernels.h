@@ -77,6 +77,8 @@ struct StepTable {            // one entry per scheduler evaluation, device resi
                               // bits 8-9 / 10-11 / 12-13: ring slots holding ets[-1] / ets[-2] / ets[-3] (before the push)
     int   save_cur;           // 1: save current sample as cur_sample before the update
     int   zero_cloth_next;    // 1: the NEXT evaluation must see zero cloth latents
+    float in_scale_next;      // scheduler.scale_model_input of the NEXT evaluation: the UNet sees latents * in_scale_next (1 for DDIM / PNDM,
+                              // 1 / sqrt(sigma^2 + 1) for LMS); the fp32 latents themselves stay unscaled
 };
 struct StepArgs {
     const h16* eps; int ld_eps;     // UNet output NHWC [2B or B][hw][ld_eps], channels 0..3 valid
@@ -97,7 +99,7 @@ int ladi_launch_sched_step(const StepArgs& a, hipStream_t st);
 // static part of the 31-channel UNet input: mask, masked-image latents, pose, cloth; uncond half zero pose/cloth
 int ladi_launch_assemble_static(h16* unet_in, int ld_in, int B, int hw, int cfg, const float* latents, const h16* mask_lat,
                                 const float* masked_lat, const h16* pose, int pose_ch, const float* cloth_lat, int has_cloth,
-                                hipStream_t st);
+                                float lat_scale, hipStream_t st);
 // posterior sample: lat[b][hw][4] = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scaling ; moments NHWC [..][ldm] (8 ch),
 // noise fp32 NCHW [B][4][h][w]
 int ladi_launch_posterior_sample(const h16* moments, int ldm, const float* noise_nchw, int B, int hw, float scaling, float* lat,

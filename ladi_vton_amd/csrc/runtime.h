@@ -283,10 +283,17 @@ struct TryOn {
     ~TryOn();
 };
 
-// scheduler tables (host): builds timesteps + StepTable entries. kind 0 = DDIM, 1 = PNDM(PLMS, skip_prk_steps)
+// scheduler tables (host): builds timesteps + StepTable entries. kind 0 = DDIM, 1 = PNDM(PLMS, skip_prk_steps), 2 = LMSDiscrete
+// (fractional timesteps, sigma parameterisation: the latents start at noise * init_noise_sigma and the UNet sees them scaled)
 void default_alphas_cumprod(std::vector<float>& ac);
+struct SchedInfo {
+    float init_noise_sigma = 1.f;    // prepare_latents: latents = noise * init_noise_sigma (tryon_pipe.py:424)
+    float in_scale0 = 1.f;           // scale_model_input of evaluation 0 (later evaluations: StepTable::in_scale_next)
+    std::vector<float> sigmas;       // LMS only: steps + 1 values (trailing 0)
+    std::vector<float> lms_coeffs;   // LMS only: [steps][4], c_ij over [d_i, d_{i-1}, d_{i-2}, d_{i-3}]
+};
 // cloth_zero_from: first evaluation index that must see zero cloth latents (tryon_pipe.py:718), computed by the caller in float64
-void build_step_table(int kind, int steps, const float* alphas_cumprod, int cloth_zero_from, std::vector<int>& timesteps,
-                      std::vector<StepTable>& table);
+void build_step_table(int kind, int steps, const float* alphas_cumprod, int cloth_zero_from, std::vector<double>& timesteps,
+                      std::vector<StepTable>& table, SchedInfo* info = nullptr);
 
 }  // namespace ladi

@@ -295,17 +295,71 @@ void default_alphas_cumprod(std::vector<float>& ac) {
     }
 }
 
-void build_step_table(int kind, int steps, const float* ac, int cloth_zero_from, std::vector<int>& timesteps,
-                      std::vector<StepTable>& table) {
+// integral over [lo, hi] of the Lagrange basis polynomial of node s[j] among s[0..order) (degree <= 3): 4-point Gauss-Legendre, exact
+static double lms_basis_integral(const double* s, int order, int j, double lo, double hi) {
+    static const double gx[4] = {-0.8611363115940526, -0.3399810435848563, 0.3399810435848563, 0.8611363115940526};
+    static const double gw[4] = {0.3478548451374538, 0.6521451548625461, 0.6521451548625461, 0.3478548451374538};
+    const double c = 0.5 * (hi + lo), h = 0.5 * (hi - lo);
+    double acc = 0.0;
+    for (int q = 0; q < 4; ++q) {
+        const double tau = c + h * gx[q];
+        double prod = 1.0;
+        for (int k = 0; k < order; ++k) if (k != j) prod *= (tau - s[k]) / (s[j] - s[k]);
+        acc += gw[q] * prod;
+    }
+    return acc * h;
+}
+
+void build_step_table(int kind, int steps, const float* ac, int cloth_zero_from, std::vector<double>& timesteps,
+                      std::vector<StepTable>& table, SchedInfo* info) {
     const int T = 1000;
     if (steps < 2 || steps > T) throw std::runtime_error("num_inference_steps out of range [2, 1000]");   // ts[steps - 2] below
+    if (kind < 0 || kind > 2) throw std::runtime_error("scheduler kind must be 0 (DDIM), 1 (PNDM) or 2 (LMSDiscrete)");
     const int ratio = T / steps;
     const double final_ac = ac[0];  // set_alpha_to_one = False
     timesteps.clear(); table.clear();
-    if (kind == 0) {
+    if (info) *info = SchedInfo();
+    if (kind == 2) {
+        // diffusers 0.14 LMSDiscreteScheduler.set_timesteps / step (order 4, epsilon prediction): timesteps = linspace(0, T-1, n)[::-1];
+        // sigma = interp(t, arange(T), sqrt((1 - a) / a)) held in fp32, trailing 0; derivative d_i = (x - (x - sigma_i eps)) / sigma_i = eps
+        std::vector<float> sig((size_t)steps + 1, 0.f);
+        for (int i = 0; i < steps; ++i) {
+            // numpy.linspace: arange(n) * ((stop - start) / (n - 1)) + start, last element set to stop exactly
+            const int k = steps - 1 - i;
+            const double t = k == steps - 1 ? (double)(T - 1) : (double)k * ((double)(T - 1) / (double)(steps - 1));
+            timesteps.push_back(t);
+            const int lo = std::min((int)t, T - 1), hi = std::min(lo + 1, T - 1);
+            const double slo = (double)(float)std::sqrt((1.0 - (double)ac[lo]) / (double)ac[lo]);
+            const double shi = (double)(float)std::sqrt((1.0 - (double)ac[hi]) / (double)ac[hi]);
+            sig[i] = (float)(slo + (shi - slo) * (t - (double)lo));
+        }
+        float smax = 0.f;
+        for (float s : sig) smax = std::max(smax, s);
+        std::vector<float> coeffs((size_t)steps * 4, 0.f);
+        for (int i = 0; i < steps; ++i) {
+            StepTable e; std::memset(&e, 0, sizeof(e));
+            const int order = std::min(i + 1, 4);
+            double nodes[4];
+            for (int k = 0; k < order; ++k) nodes[k] = (double)sig[i - k];
+            for (int j = 0; j < order; ++j) {
+                e.w[j] = (float)lms_basis_integral(nodes, order, j, (double)sig[i], (double)sig[i + 1]);
+                coeffs[(size_t)i * 4 + j] = e.w[j];
+            }
+            e.c_x = 1.f; e.c_e = 1.f;
+            const int slot = i & 3, s1 = (i - 1) & 3, s2 = (i - 2) & 3, s3 = (i - 3) & 3;
+            e.push = 1 | (slot << 4) | (s1 << 8) | (s2 << 10) | (s3 << 12);
+            e.in_scale_next = i + 1 < steps ? (float)(1.0 / std::sqrt((double)sig[i + 1] * (double)sig[i + 1] + 1.0)) : 1.f;
+            table.push_back(e);
+        }
+        if (info) {
+            info->init_noise_sigma = smax;
+            info->in_scale0 = (float)(1.0 / std::sqrt((double)sig[0] * (double)sig[0] + 1.0));
+            info->sigmas = sig; info->lms_coeffs = coeffs;
+        }
+    } else if (kind == 0) {
         for (int i = steps - 1; i >= 0; --i) timesteps.push_back(i * ratio + 1);
         for (int i = 0; i < steps; ++i) {
-            const int t = timesteps[i], tp = t - ratio;
+            const int t = (int)timesteps[i], tp = t - ratio;
             const double a_t = ac[t], a_p = tp >= 0 ? (double)ac[tp] : final_ac;
             StepTable e; std::memset(&e, 0, sizeof(e));
             e.c_x = (float)std::sqrt(a_p / a_t);
@@ -323,7 +377,7 @@ void build_step_table(int kind, int steps, const float* ac, int cloth_zero_from,
         for (int i = (int)seq.size() - 1; i >= 0; --i) timesteps.push_back(seq[i]);
         int npush = 0;  // number of pushes so far
         for (int i = 0; i < (int)timesteps.size(); ++i) {
-            int t = timesteps[i], tp = t - ratio;
+            int t = (int)timesteps[i], tp = t - ratio;
             StepTable e; std::memset(&e, 0, sizeof(e));
             const int counter = i;
             int hist = npush;  // entries available before this evaluation
@@ -352,6 +406,7 @@ void build_step_table(int kind, int steps, const float* ac, int cloth_zero_from,
             table.push_back(e);
         }
     }
+    if (kind != 2) for (auto& e : table) e.in_scale_next = 1.f;
     // `if i >= num_inference_steps - cloth_conditioning_steps: cloth = 0` (tryon_pipe.py:718-719), evaluated at the
     // START of evaluation i -> mark entry i-1 so that the step kernel zeroes the cloth channels for evaluation i.
     for (int i = 1; i < (int)table.size(); ++i)

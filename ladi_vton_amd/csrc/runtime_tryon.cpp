@@ -62,8 +62,8 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
     // ---- scheduler tables (host)
     std::vector<float> ac;
     if (in.alphas_cumprod) ac.assign(in.alphas_cumprod, in.alphas_cumprod + 1000); else default_alphas_cumprod(ac);
-    std::vector<int> timesteps; std::vector<StepTable> table;
-    build_step_table(in.scheduler, in.steps, ac.data(), in.cloth_zero_from, timesteps, table);
+    std::vector<double> timesteps; std::vector<StepTable> table; SchedInfo sinfo;
+    build_step_table(in.scheduler, in.steps, ac.data(), in.cloth_zero_from, timesteps, table, &sinfo);
     const int evals = (int)timesteps.size();
     const bool cloth_zero_from_start = has_cloth && in.cloth_zero_from <= 0;
     last_evals = evals;
@@ -136,8 +136,8 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
                 if (!c.dry()) c.check(ladi_launch_posterior_sample(mom.p, mom.ld, in.noise_cloth, B, hw, vae->cfg.scaling_factor, cloth_lat, st), "posterior");
                 arena.release(mk);
             }
-            // ---------------- 6. initial latents (RNG draw #2), init_noise_sigma = 1
-            if (!c.dry()) c.check(ladi_launch_lat_nchw_to_pix(in.noise_latents, B, hw, 1.0f, latents, st), "latents");
+            // ---------------- 6. initial latents (RNG draw #2) * init_noise_sigma (1 for DDIM / PNDM; tryon_pipe.py:424)
+            if (!c.dry()) c.check(ladi_launch_lat_nchw_to_pix(in.noise_latents, B, hw, sinfo.init_noise_sigma, latents, st), "latents");
             // ---------------- 7. masked-image latents (RNG draw #3) + EMASC skips
             {
                 Act feats[5];
@@ -154,7 +154,8 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
             // ---------------- 7a. static UNet input channels
             if (!c.dry()) {
                 c.check(ladi_launch_assemble_static(unet_in.p, 64, B, hw, cfgf, latents, mask8, masked_lat, pose_lat, pose_ch,
-                                                    (has_cloth && !cloth_zero_from_start) ? cloth_lat : nullptr, has_cloth ? 1 : 0, st), "assemble");
+                                                    (has_cloth && !cloth_zero_from_start) ? cloth_lat : nullptr, has_cloth ? 1 : 0,
+                                                    sinfo.in_scale0, st), "assemble");
                 HIP_OK(hipEventRecord(ev[1], st));
             }
             // ---------------- 9. denoising loop

@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from ._lib import TryOnInputs, check, dtype_code, ptr, stream_ptr
 from .modules import NativeEMASC, NativeUNet, NativeVAE, mask_features
-from .schedulers import DDIMScheduler, PNDMScheduler
+from .schedulers import DDIMScheduler, LMSDiscreteScheduler, PNDMScheduler
 
 
 def numpy_to_pil(images):
@@ -156,7 +156,7 @@ class StableDiffusionTryOnePipeline:
         else:
             n_cloth, n_lat, n_mask = [t.to(device=device, dtype=torch.float32).contiguous() if t is not None else None for t in noise]
         native = isinstance(self.unet, NativeUNet) and isinstance(self.vae, NativeVAE) and (self.emasc is None or isinstance(self.emasc, NativeEMASC))
-        can_fuse = (fused and native and callback is None and isinstance(self.scheduler, (DDIMScheduler, PNDMScheduler)) and eta == 0.0
+        can_fuse = (fused and native and callback is None and isinstance(self.scheduler, (DDIMScheduler, PNDMScheduler, LMSDiscreteScheduler)) and eta == 0.0
                     and (not self.emasc or list(self.emasc_int_layers or []) == [1, 2, 3, 4, 5]))
         if can_fuse:
             images = self._run_fused(image, mask_image, pose_map, warped_cloth if cloth_input_type == "warped" else None, pe, neg,

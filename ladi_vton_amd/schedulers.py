@@ -1,6 +1,7 @@
-"""Host-side mirrors of the two schedulers the reference pipeline accepts (diffusers 0.14.0 DDIMScheduler — what
-src/inference.py:123-124 instantiates — and PNDMScheduler with skip_prk_steps, which the SD2-inpainting scheduler_config.json
-describes).  They expose the attributes tryon_pipe.py touches (:74,88,331-346,650-651,711,722,740).
+"""Host-side mirrors of the three schedulers the reference pipeline accepts (tryon_pipe.py:62: diffusers 0.14.0 DDIMScheduler — what
+src/inference.py:123-124 instantiates —, PNDMScheduler with skip_prk_steps, which the SD2-inpainting scheduler_config.json
+describes, and LMSDiscreteScheduler).  They expose the attributes tryon_pipe.py touches
+(:74,88,331-346,424,650-651,711,722,740).
 
 The fused native loop (ladi_tryon_run) does not call .step(): it consumes the same tables on the device.  .step() here serves
 the module-by-module drop-in path and operates on small [B,4,h,w] tensors.
@@ -11,7 +12,7 @@ import torch
 
 from . import _lib
 
-DDIM, PNDM = 0, 1
+DDIM, PNDM, LMS = 0, 1, 2
 
 
 def _alphas_cumprod():
@@ -108,4 +109,54 @@ class PNDMScheduler(_SchedulerBase):
         denom = a_t * (1 - a_p) ** 0.5 + (a_t * (1 - a_t) * a_p) ** 0.5
         prev = (a_p / a_t) ** 0.5 * x - (a_p - a_t) * e / denom
         self.counter += 1
+        return SimpleNamespace(prev_sample=prev.to(sample.dtype))
+
+
+class LMSDiscreteScheduler(_SchedulerBase):
+    """diffusers 0.14 LMSDiscreteScheduler (order-4 linear multistep in the sigma parameterisation, epsilon prediction).  The
+    fractional timesteps, the sigmas and the multistep weights all come from the native table builder (ladi_sched_lms), i.e. they
+    are the very numbers the fused device loop uses."""
+    kind = LMS
+
+    def __init__(self):
+        super().__init__()
+        self.sigmas = None
+        self.init_noise_sigma = float(((1 - self.alphas_cumprod) / self.alphas_cumprod).sqrt().max())   # as diffusers before set_timesteps
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        import ctypes
+        n = int(num_inference_steps)
+        ts = (ctypes.c_double * n)()
+        sg = (ctypes.c_float * (n + 1))()
+        cf = (ctypes.c_float * (4 * n))()
+        ac = self.alphas_cumprod.to("cpu", torch.float32).contiguous()      # the same table the fused loop receives
+        if _lib.load().ladi_sched_lms(n, ctypes.c_void_p(ac.data_ptr()), ts, sg, cf) < 0:
+            raise _lib.NativeError("ladi_sched_lms: " + _lib.last_error())
+        self.num_inference_steps = n
+        self.timesteps = torch.tensor(list(ts), dtype=torch.float64, device=device)
+        self.sigmas = torch.tensor(list(sg), dtype=torch.float32)
+        self._coeffs = [list(cf[4 * i:4 * i + 4]) for i in range(n)]
+        self._ts = list(ts)
+        self.init_noise_sigma = float(self.sigmas.max())
+        self.derivatives = []
+
+    def _index(self, timestep):
+        t = float(timestep)
+        return min(range(len(self._ts)), key=lambda i: abs(self._ts[i] - t))
+
+    def scale_model_input(self, sample, timestep=None):
+        sigma = float(self.sigmas[self._index(timestep)])
+        return sample / ((sigma * sigma + 1.0) ** 0.5)
+
+    def step(self, model_output, timestep, sample, order=4, **kw):
+        if order != 4:
+            raise NotImplementedError("LMSDiscreteScheduler.step: only the default order = 4 is supported")
+        i = self._index(timestep)
+        sigma = float(self.sigmas[i])
+        x, e = sample.float(), model_output.float()
+        x0 = x - sigma * e
+        self.derivatives = (self.derivatives + [(x - x0) / sigma])[-4:]
+        prev = x
+        for c, d in zip(self._coeffs[i][:min(i + 1, 4)], reversed(self.derivatives)):
+            prev = prev + c * d
         return SimpleNamespace(prev_sample=prev.to(sample.dtype))

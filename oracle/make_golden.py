@@ -72,6 +72,7 @@ def main():
     make_vision_golden(g)
     make_warp_golden()
     make_wiring_golden()
+    make_wiring_lms_golden()
     make_dataset_golden()
     print("wrote", os.listdir(OUT))
 
@@ -168,6 +169,33 @@ WIRING_CASES = [   # (name, scheduler, steps, cloth_cond_rate, guidance, emasc, 
     ("pndm_ccr", "pndm", 5, 0.4, 7.5, True, "warped", False),           # cloth zeroed from evaluation i >= 5 - 3.0 = 2
     ("ddim_nocfg", "ddim", 3, 0.5, 1.0, False, "warped", True),         # no CFG, no EMASC, no_pose
 ]
+WIRING_CASES_LMS = [   # separate fixture (ref_wiring_lms.safetensors): init_noise_sigma / scale_model_input placement (tryon_pipe.py:424,722)
+    ("lms_full", "lms", 5, 0.5, 7.5, True, "warped", False),          # fractional timesteps 749.25 / 499.5 / 249.75; cloth zero from i = 3
+]
+
+
+def _run_wiring_cases(RH, cases, blob, ucfg, usd, vae, emasc, inp):
+    """the REAL StableDiffusionTryOnePipeline.__call__ for each case; records images, every assembled UNet input, timesteps, prompt batch"""
+    with torch.no_grad():
+        for name, sched, steps, ccr, gscale, use_emasc, cit, no_pose in cases:
+            unet = RH.OracleUNet(ucfg, usd)
+            sch = {"ddim": RH.DDIMScheduler, "pndm": RH.PNDMScheduler, "lms": RH.LMSDiscreteScheduler}[sched]()
+            pipe = RH.real_pipeline(unet, vae, sch, emasc if use_emasc else None, [1, 2, 3, 4, 5] if use_emasc else None)
+            pipe.text_encoder = type("T", (), {"dtype": torch.float32})()
+            gen = torch.Generator().manual_seed(1234)
+            mask = inp["mask_image"].clone()
+            res = pipe(image=inp["image"].clone(), mask_image=mask, pose_map=inp["pose_map"].clone(), warped_cloth=inp["warped_cloth"].clone(),
+                       prompt_embeds=inp["prompt_embeds"].clone(), negative_prompt_embeds=inp["negative_prompt_embeds"].clone(),
+                       height=128, width=64, num_inference_steps=steps, guidance_scale=gscale, generator=gen, output_type="np",
+                       cloth_cond_rate=ccr, no_pose=no_pose, cloth_input_type=cit)
+            blob["pipe.%s.images" % name] = torch.from_numpy(res.images)[:, ::2, ::2].contiguous()
+            blob["pipe.%s.unet_in" % name] = torch.stack([c[0] for c in unet.calls]).contiguous()
+            if sched == "lms":
+                blob["pipe.%s.timesteps" % name] = torch.tensor([float(c[1]) for c in unet.calls], dtype=torch.float64)
+            else:
+                blob["pipe.%s.timesteps" % name] = torch.tensor([c[1] for c in unet.calls], dtype=torch.int32)
+            blob["pipe.%s.ehs" % name] = unet.calls[0][2].contiguous()
+            blob["pipe.%s.mask_after" % name] = mask.contiguous()                     # binarised in place by the reference
 
 
 def make_wiring_golden():
@@ -214,25 +242,28 @@ def make_wiring_golden():
             first = lst[0]
             blob["dec." + name] = sub(vae.decode(z.clone(), intermediate_features=lst, int_layers=layers).sample)
             assert lst[-1] is first, "Decoder.forward reverses the caller's list in place (vae.py:190)"
-        # ---- the whole pipeline
-        for name, sched, steps, ccr, gscale, use_emasc, cit, no_pose in WIRING_CASES:
-            unet = RH.OracleUNet(ucfg, usd)
-            sch = RH.DDIMScheduler() if sched == "ddim" else RH.PNDMScheduler()
-            pipe = RH.real_pipeline(unet, vae, sch, emasc if use_emasc else None, [1, 2, 3, 4, 5] if use_emasc else None)
-            pipe.text_encoder = type("T", (), {"dtype": torch.float32})()
-            gen = torch.Generator().manual_seed(1234)
-            mask = inp["mask_image"].clone()
-            res = pipe(image=inp["image"].clone(), mask_image=mask, pose_map=inp["pose_map"].clone(), warped_cloth=inp["warped_cloth"].clone(),
-                       prompt_embeds=inp["prompt_embeds"].clone(), negative_prompt_embeds=inp["negative_prompt_embeds"].clone(),
-                       height=128, width=64, num_inference_steps=steps, guidance_scale=gscale, generator=gen, output_type="np",
-                       cloth_cond_rate=ccr, no_pose=no_pose, cloth_input_type=cit)
-            blob["pipe.%s.images" % name] = torch.from_numpy(res.images)[:, ::2, ::2].contiguous()
-            blob["pipe.%s.unet_in" % name] = torch.stack([c[0] for c in unet.calls]).contiguous()
-            blob["pipe.%s.timesteps" % name] = torch.tensor([c[1] for c in unet.calls], dtype=torch.int32)
-            blob["pipe.%s.ehs" % name] = unet.calls[0][2].contiguous()
-            blob["pipe.%s.mask_after" % name] = mask.contiguous()                     # binarised in place by the reference
+    _run_wiring_cases(RH, WIRING_CASES, blob, ucfg, usd, vae, emasc, inp)
     blob = {k: (v.half() if k.endswith("unet_in") else v) for k, v in blob.items()}   # keep the fixture small
     save_file(blob, os.path.join(OUT, "ref_wiring.safetensors"))
+
+
+def make_wiring_lms_golden():
+    """tests/golden/ref_wiring_lms.safetensors: the REAL pipeline driven with an LMSDiscreteScheduler (oracle LMS behind the diffusers
+    interface): pins init_noise_sigma on the initial latents and scale_model_input on the 4 latent channels of every UNet input"""
+    from oracle import ref_harness as RH
+    from ladi_vton_amd import configs as C
+    RH.install()
+    from src.models.emasc import EMASC
+    vcfg, ucfg = C.VAE_TINY, C.UNET_TINY
+    ecfg = C.emasc_for_vae(vcfg)
+    vae = RH.real_autoencoder_kl(vcfg, C.synth_state_dict(C.vae_shapes(vcfg), "vae."))
+    emasc = EMASC(list(ecfg["in_channels"]), list(ecfg["out_channels"]), kernel_size=3, padding=1, stride=1, type="nonlinear").eval()
+    emasc.load_state_dict(C.synth_state_dict(C.emasc_shapes(ecfg), "emasc."), strict=True)
+    inp, _, _ = wiring_inputs()
+    blob = {}
+    _run_wiring_cases(RH, WIRING_CASES_LMS, blob, ucfg, C.synth_state_dict(C.unet_shapes(ucfg), "unet."), vae, emasc, inp)
+    blob = {k: (v.half() if k.endswith("unet_in") else v) for k, v in blob.items()}
+    save_file(blob, os.path.join(OUT, "ref_wiring_lms.safetensors"))
 
 
 DATASET_KEYS = ("image", "cloth", "pose_map", "im_mask", "inpaint_mask", "parse_mask_total")

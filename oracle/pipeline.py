@@ -95,7 +95,74 @@ class PNDM:
         return out
 
 
+class LMS:
+    """diffusers 0.14.0 LMSDiscreteScheduler(beta_schedule="scaled_linear", epsilon prediction) -- the third scheduler type
+    StableDiffusionTryOnePipeline accepts (src/vto_pipelines/tryon_pipe.py:62).  diffusers is not installed here, so this restates
+    the published algorithm (Katherine Crowson's k-diffusion linear multistep sampler as diffusers ships it):
+      set_timesteps : timesteps = linspace(0, T-1, n)[::-1] (fractional, float64); sigma(t) = interp of sqrt((1-a)/a) (float32),
+                      a trailing sigma 0; init_noise_sigma = max sigma
+      scale_model_input : sample / sqrt(sigma_i^2 + 1)
+      step          : derivative d_i = (sample - pred_x0) / sigma_i with pred_x0 = sample - sigma_i * eps; order = min(i + 1, 4);
+                      prev = sample + sum_j c_ij * d_{i-j},  c_ij = integral over [sigma_i, sigma_{i+1}] of the Lagrange basis
+                      polynomial of node sigma_{i-j} among {sigma_i .. sigma_{i-order+1}} (scipy.integrate.quad, epsrel 1e-4)
+    Known-answer anchor (tests/test_cpu.py): init_noise_sigma = 14.6146 for the SD beta schedule."""
+    order = 1
+
+    def __init__(self):
+        self.ac = alphas_cumprod()
+
+    def set_timesteps(self, n):
+        import numpy as np
+        self.n = n
+        ts = np.linspace(0, 999, n, dtype=float)[::-1].copy()
+        sig = (((1 - self.ac) / self.ac) ** 0.5).numpy()                      # float32, as diffusers holds it
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        self.sigmas = np.concatenate([sig, [0.0]]).astype(np.float32)
+        self.timesteps = [float(t) for t in ts]
+        self.init_noise_sigma = float(self.sigmas.max())
+        self.derivatives = []
+        self._i = 0
+
+    def scale_model_input(self, x, t):
+        i = self.timesteps.index(float(t))
+        return x / ((float(self.sigmas[i]) ** 2 + 1) ** 0.5)
+
+    def coefficient(self, order, i, j):
+        from scipy import integrate
+        s = [float(v) for v in self.sigmas]
+
+        def basis(tau):
+            prod = 1.0
+            for k in range(order):
+                if k != j:
+                    prod *= (tau - s[i - k]) / (s[i - j] - s[i - k])
+            return prod
+
+        return integrate.quad(basis, s[i], s[i + 1], epsrel=1e-4)[0]
+
+    def step(self, eps, t, x, order=4):
+        i = self.timesteps.index(float(t))
+        sigma = float(self.sigmas[i])
+        x0 = x - sigma * eps
+        self.derivatives.append((x - x0) / sigma)
+        if len(self.derivatives) > order:
+            self.derivatives.pop(0)
+        order = min(i + 1, order)
+        coeffs = [self.coefficient(order, i, j) for j in range(order)]
+        return x + sum(c * d for c, d in zip(coeffs, reversed(self.derivatives)))
+
+
+def _identity_scale(self, x, t):
+    return x
+
+
+DDIM.scale_model_input = _identity_scale
+PNDM.scale_model_input = _identity_scale
+
+
 def make_scheduler(kind):
+    if kind in (2, "lms"):
+        return LMS()
     return DDIM() if kind in (0, "ddim") else PNDM()
 
 
@@ -199,6 +266,7 @@ def tryon_pipeline(unet_sd, unet_cfg, vae_sd, vae_cfg, emasc_sd, inp, num_infere
         x = torch.cat([latents] * 2) if do_cfg else latents
         if cloth_latents is not None and i >= (num_inference_steps - cloth_conditioning_steps):
             cloth_latents = torch.zeros_like(cloth_latents)
+        x = sch.scale_model_input(x, t)                     # tryon_pipe.py:722 (identity for DDIM / PNDM)
         parts = [x, mask_lat, masked_lat_in, pose]
         if cloth_latents is not None:
             parts.append(cloth_latents)

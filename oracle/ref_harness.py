@@ -275,12 +275,12 @@ class _SchedBase(ConfigMixin):
 
     def __init__(self):
         from . import pipeline as P
-        self._impl = P.DDIM() if self.kind == "ddim" else P.PNDM()
+        self._impl = P.make_scheduler(self.kind)
         self._internal_dict = FrozenDict(steps_offset=1, skip_prk_steps=True, num_train_timesteps=1000)
 
     def set_timesteps(self, n, device=None):
         self._impl.set_timesteps(n)
-        self.timesteps = torch.tensor(self._impl.timesteps, dtype=torch.int64)
+        self.timesteps = torch.tensor(self._impl.timesteps, dtype=torch.float64 if self.kind == "lms" else torch.int64)
 
     def scale_model_input(self, sample, timestep=None):
         return sample
@@ -302,7 +302,19 @@ class PNDMScheduler(_SchedBase):
 
 
 class LMSDiscreteScheduler(_SchedBase):
-    kind = "ddim"
+    """the oracle's LMS restatement behind the diffusers interface: what this pins is how the REAL pipeline uses the scheduler
+    (init_noise_sigma at tryon_pipe.py:424, scale_model_input on the 4 latent channels only at :722), not the LMS arithmetic"""
+    kind = "lms"
+
+    @property
+    def init_noise_sigma(self):
+        return getattr(self._impl, "init_noise_sigma", 14.614646911621094)
+
+    def scale_model_input(self, sample, timestep=None):
+        return self._impl.scale_model_input(sample, float(timestep))
+
+    def step(self, model_output, timestep, sample, order=4, return_dict=True):
+        return _SchedOut(self._impl.step(model_output, float(timestep), sample, order=order))
 
 
 _installed = False
@@ -359,6 +371,9 @@ def install():
         return
     if "diffusers" in sys.modules:
         raise RuntimeError("a real diffusers is already imported")
+    # tryon_pipe.py imports these lazily-loaded transformers classes; resolve them while torchvision is still truly absent (transformers
+    # probes it with importlib.util.find_spec, which a spec-less stand-in module breaks)
+    from transformers import CLIPTextModel, CLIPTokenizer  # noqa: F401
 
     def mod(name, **attrs):
         m = types.ModuleType(name)
@@ -409,8 +424,10 @@ class OracleUNet:
 
     def __call__(self, sample, timestep, encoder_hidden_states=None):
         from . import models as M
-        self.calls.append((sample.clone(), int(timestep), encoder_hidden_states.clone()))
-        return types.SimpleNamespace(sample=M.unet_forward(self.sd, self.cfg, sample, int(timestep), encoder_hidden_states))
+        t = float(timestep)
+        t = int(t) if t == int(t) else t                    # LMS timesteps are fractional
+        self.calls.append((sample.clone(), t, encoder_hidden_states.clone()))
+        return types.SimpleNamespace(sample=M.unet_forward(self.sd, self.cfg, sample, t, encoder_hidden_states))
 
 
 def real_pipeline(unet, vae, scheduler, emasc=None, int_layers=None):

@@ -6,6 +6,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 from safetensors.torch import load_file
@@ -97,19 +98,20 @@ def test_oracle_matches_real_reference_pipeline():
     it assembled (CFG order [uncond; cond], 31-channel order, zero pose / cloth in the uncond half, cloth zeroing from
     `i >= steps - (1 - rate) * steps` including PNDM's extra evaluation), the prompt batch, the in-place mask binarisation and
     the decoded images; the oracle pipeline must retrace all of it from the same three RNG draws"""
-    from oracle.make_golden import WIRING_CASES, wiring_inputs
+    from oracle.make_golden import WIRING_CASES, WIRING_CASES_LMS, wiring_inputs
     g = load_file(os.path.join(GOLD, "ref_wiring.safetensors"))
+    g.update(load_file(os.path.join(GOLD, "ref_wiring_lms.safetensors")))      # LMS: init_noise_sigma / scale_model_input placement
     vcfg, ucfg = C.VAE_TINY, C.UNET_TINY
     ecfg = C.emasc_for_vae(vcfg)
     vsd = C.synth_state_dict(C.vae_shapes(vcfg), "vae.")
     usd = C.synth_state_dict(C.unet_shapes(ucfg), "unet.")
     esd = C.synth_state_dict(C.emasc_shapes(ecfg), "emasc.")
-    for name, sched, steps, ccr, gscale, use_emasc, cit, no_pose in WIRING_CASES:
+    for name, sched, steps, ccr, gscale, use_emasc, cit, no_pose in WIRING_CASES + WIRING_CASES_LMS:
         inp, _, _ = wiring_inputs()
         calls = []
 
         def unet_fn(x, t, e):
-            calls.append((x.clone(), int(t), e.clone()))
+            calls.append((x.clone(), float(t) if sched == "lms" else int(t), e.clone()))
             return M.unet_forward(usd, ucfg, x, t, e)
 
         img, _ = P.tryon_pipeline(usd, ucfg, vsd, vcfg, esd if use_emasc else None, inp, num_inference_steps=steps, guidance_scale=gscale,
@@ -120,6 +122,11 @@ def test_oracle_matches_real_reference_pipeline():
         assert torch.equal(calls[0][2], g["pipe.%s.ehs" % name]), name
         got_in = torch.stack([c[0] for c in calls])
         assert got_in.shape == ref_in.shape and got_in.shape[2] == 31
+        if sched == "lms":      # the 4 latent channels of evaluation 0 are noise * init_noise_sigma / sqrt(sigma_0^2 + 1), nothing else is scaled
+            s0 = 14.614646911621094
+            want0 = inp["noise_latents"] * s0 / (s0 * s0 + 1) ** 0.5
+            assert torch.allclose(ref_in[0, ref_in.shape[1] // 2:, 0:4], want0.half().float(), atol=2e-3, rtol=2e-3)
+            assert any(t != int(t) for t in g["pipe.%s.timesteps" % name].tolist())      # fractional timesteps reach the UNet
         # fixture inputs are stored in fp16: compare at that resolution (relative 1e-3), channel group by channel group
         for lo, hi in ((0, 4), (4, 5), (5, 9), (9, 27), (27, 31)):
             a, b = got_in[:, :, lo:hi], ref_in[:, :, lo:hi]
@@ -260,6 +267,48 @@ def test_native_host_scheduler_tables_match_oracle(lib):
     ac = P.alphas_cumprod()
     got = torch.tensor(list(out))
     assert float(((got - ac).abs() / ac).max()) < 5e-6
+
+
+def test_lms_scheduler_tables_and_host_step_match_oracle(lib):
+    """LMSDiscreteScheduler (the third scheduler tryon_pipe.py:62 accepts): native table builder (closed-form Gauss-Legendre integrals of
+    the Lagrange basis) vs the oracle's restatement of diffusers 0.14 (scipy quad, epsrel 1e-4); known-answer anchors of the algorithm:
+    init_noise_sigma = 14.6146 for the SD beta schedule, sum_j c_ij = sigma_{i+1} - sigma_i (the basis polynomials sum to 1), first step
+    = one Euler step; then the host-side shim's scale_model_input / step vs the oracle on a random trajectory"""
+    import ladi_vton_amd as L
+    for n in (5, 20, 50):
+        ts, sg, cf = (ctypes.c_double * n)(), (ctypes.c_float * (n + 1))(), (ctypes.c_float * (4 * n))()
+        ac = P.alphas_cumprod().contiguous()
+        assert lib.ladi_sched_lms(n, ctypes.c_void_p(ac.data_ptr()), ts, sg, cf) == n
+        o = P.make_scheduler("lms"); o.set_timesteps(n)
+        assert list(ts) == o.timesteps                                         # float64 linspace, bit-equal
+        assert np.allclose(np.array(list(sg)), o.sigmas, rtol=2e-6, atol=0)
+        assert abs(sg[0] - 14.6146) < 1e-3 and sg[n] == 0.0
+        co = np.array(list(cf)).reshape(n, 4)
+        for i in range(n):
+            order = min(i + 1, 4)
+            want = [o.coefficient(order, i, j) for j in range(order)]
+            assert np.allclose(co[i, :order], want, rtol=2e-4, atol=2e-6), (n, i)
+            assert not co[i, order:].any()
+            assert abs(co[i].sum() - (o.sigmas[i + 1] - o.sigmas[i])) < 1e-4 * abs(o.sigmas[i])
+        assert abs(co[0, 0] - (o.sigmas[1] - o.sigmas[0])) < 1e-5 * abs(o.sigmas[0])        # Euler
+    with pytest.raises(Exception):
+        buf = (ctypes.c_int * 64)()
+        assert lib.ladi_sched_timesteps(2, 20, buf, 64) >= 0                  # fractional timesteps have their own entry point
+    n = 12
+    s, o = L.LMSDiscreteScheduler(), P.make_scheduler("lms")
+    assert abs(s.init_noise_sigma - 14.6146) < 1e-3                            # available before set_timesteps, as in diffusers
+    s.set_timesteps(n); o.set_timesteps(n)
+    assert s.timesteps.dtype == torch.float64 and s.timesteps.tolist() == o.timesteps
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 4, 8, 6), generator=g) * s.init_noise_sigma
+    xo = x.clone()
+    for t in s.timesteps:
+        assert torch.allclose(s.scale_model_input(x, t), o.scale_model_input(xo, float(t)), rtol=1e-5, atol=1e-6)
+        e = torch.randn((2, 4, 8, 6), generator=g)
+        x, xo = s.step(e, t, x).prev_sample, o.step(e, float(t), xo)
+        assert torch.allclose(x, xo, rtol=1e-4, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        s.step(e, s.timesteps[0], x, order=2)
 
 
 def test_no_cpu_fallback():

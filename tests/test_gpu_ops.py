@@ -433,9 +433,10 @@ def test_layout_roundtrip(lib):
     assert torch.equal(nh[..., :C].float().cpu(), x.permute(0, 2, 3, 1))
 
 
-@pytest.mark.parametrize("kind,steps", [(0, 50), (1, 50), (0, 20), (1, 7)])
+@pytest.mark.parametrize("kind,steps", [(0, 50), (1, 50), (0, 20), (1, 7), (2, 50), (2, 7)])
 def test_scheduler_device_vs_oracle(lib, kind, steps):
-    """fused CFG + DDIM / PLMS update on the device vs the oracle's scheduler; tolerance: fp32 rounding (rel <= 1e-5)"""
+    """fused CFG + DDIM / PLMS / LMS update on the device vs the oracle's scheduler; tolerance: fp32 rounding (rel <= 1e-5; LMS 1e-4: its
+    weights come from a closed-form integral here and from scipy quad at epsrel 1e-4 in the oracle, as in diffusers)"""
     from oracle import pipeline as P
     sch = P.make_scheduler(kind)
     sch.set_timesteps(steps)
@@ -443,7 +444,7 @@ def test_scheduler_device_vs_oracle(lib, kind, steps):
     B, hw, gs = 2, 96, 7.5
     g = torch.Generator().manual_seed(51)
     eps = torch.randn((evals, 2 * B, hw, 4), generator=g).half()
-    lat0 = torch.randn((B, hw, 4), generator=g)
+    lat0 = torch.randn((B, hw, 4), generator=g) * sch.init_noise_sigma
     x = lat0.clone()
     for i, t in enumerate(sch.timesteps):
         e = eps[i].float()
@@ -454,7 +455,7 @@ def test_scheduler_device_vs_oracle(lib, kind, steps):
     rc = lib.ladi_op_sched_run(kind, steps, ctypes.c_void_p(ac.data_ptr()), ptr(E), evals, B, hw, 1, gs, ptr(L), stream_ptr())
     assert rc == 0, _lib.last_error()
     torch.cuda.synchronize()
-    assert U.rel_l2(L.cpu(), x) < 1e-5
+    assert U.rel_l2(L.cpu(), x) < (1e-4 if kind == 2 else 1e-5)
 
 
 # --------------------------------------------------------------------------------------------------------------- pipeline pre-processing (§8 a10)
