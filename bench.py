@@ -71,7 +71,7 @@ def parse():
     p.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[] index")
     p.add_argument("--batch", type=int, default=None, help="override: try-on pairs per GPU (weak scaling)")
     p.add_argument("--inference-steps", type=int, default=None)
-    p.add_argument("--scheduler", default=None, choices=["pndm", "ddim"])
+    p.add_argument("--scheduler", default=None, choices=["pndm", "ddim", "lms"])
     p.add_argument("--height", type=int, default=None)
     p.add_argument("--width", type=int, default=None)
     p.add_argument("--size", default="full", choices=["full", "tiny"])
@@ -296,7 +296,7 @@ def main():
         vision = L.NativeCLIPVisionEncoder(C.VISION_FULL, C.synth_items(C.vision_shapes(C.VISION_FULL), "vision."))
         adapter = L.NativeInversionAdapter(C.ADAPTER_FULL, C.synth_items(C.adapter_shapes(C.ADAPTER_FULL), "adapter."))
         text = L.NativeCLIPTextEncoder(C.TEXT_FULL, C.synth_items(C.text_shapes(C.TEXT_FULL), "text."))
-    sch = L.DDIMScheduler() if scheduler == "ddim" else L.PNDMScheduler()
+    sch = {"ddim": L.DDIMScheduler, "pndm": L.PNDMScheduler, "lms": L.LMSDiscreteScheduler}[scheduler]()
     pipe = L.StableDiffusionTryOnePipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, scheduler=sch, emasc=emasc,
                                            emasc_int_layers=[1, 2, 3, 4, 5])
     t_build = time.time() - t_build

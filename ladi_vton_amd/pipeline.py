@@ -140,8 +140,11 @@ class StableDiffusionTryOnePipeline:
             raise ValueError("`mask_image` input cannot be undefined.")
         if cloth_input_type not in ("warped", "none"):
             raise ValueError(f"Invalid cloth_input_type {cloth_input_type}")
-        if num_images_per_prompt != 1:
-            raise NotImplementedError("num_images_per_prompt != 1 is not supported")
+        # num_images_per_prompt = k repeats every prompt k times (tryon_pipe.py:259-260,309-310) and sizes the latents for B * k samples
+        # (:659); the reference concatenates image-derived tensors (pose map, warped cloth) unrepeated (:724-729), so the only inputs it
+        # can run are image batches that already hold B * k samples -- the same rule applies here (shape checks below)
+        if not isinstance(num_images_per_prompt, int) or num_images_per_prompt < 1:
+            raise ValueError("num_images_per_prompt must be a positive integer")
         device = self._execution_device
         do_cfg = guidance_scale > 1.0
         pe, neg = self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt, prompt_embeds, negative_prompt_embeds)

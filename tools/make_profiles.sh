@@ -12,6 +12,7 @@ rm -f $LADI_TUNE_CACHE
 timeout 900 python bench.py --cpu-runs 3 --steps 10 --warmup 3 > $O/r02_bench_default.json 2> $O/r02_bench_default.err
 timeout 300 python bench.py --config 2 --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > $O/r02_bench_config2.json 2>/dev/null
 timeout 300 python bench.py --scheduler ddim --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $O/r02_bench_ddim.json 2>/dev/null
+timeout 300 python bench.py --scheduler lms --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $O/r02_bench_lms.json 2>/dev/null
 timeout 400 python bench.py --config 4 --no-cpu-baseline --no-roofline --steps 1 --warmup 1 > $O/r02_bench_config4.json 2>/dev/null
 timeout 300 python bench.py --roofline-only --no-cpu-baseline > $O/r02_bench_roofline_only.json 2>/dev/null
 # 2. kernel traces (tuned selections preloaded: no tuning launches in the traces)
