@@ -5,6 +5,8 @@ whole path (GroupNorm / LayerNorm / attention are per-sample, CFG pairs stay on 
 The reference has no working multi-GPU inference path (src/inference.py:92-94 reads an undefined args.local_rank).
 Noise is drawn for the GLOBAL batch and sliced per rank so results do not depend on the world size.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -30,7 +32,9 @@ def to_uint8(images):
 
 def all_gather_images(local_u8, batch, group=None):
     """all-gather of per-rank [b_r, H, W, 3] uint8 shards into [batch, H, W, 3] on every rank (padded to the largest shard)"""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
+        return local_u8
+    if dist.get_world_size(group) == 1 and os.environ.get("LADI_FORCE_COLLECTIVE") != "1":   # the switch lets a 1-GPU box exercise RCCL
         return local_u8
     world = dist.get_world_size(group)
     sizes = [shard_bounds(batch, r, world) for r in range(world)]
