@@ -218,7 +218,7 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(sds, cfgs, runs, target_evals, scheduler):
+def cpu_baseline(sds, cfgs, runs, target_evals, scheduler, size="full"):
     """BASELINE configs[0] (B = 1, 20 scheduler steps, 512x384, CFG 7.5, EMASC on) END TO END through the fp32 CPU oracle (a port: the
     reference itself is not importable here) on this box's host cores; median over `runs`.  images/s for the metric's
     step count = 1 / (t_run + (target_evals - evals_20) * mean UNet evaluation time of the same run)."""
@@ -248,7 +248,7 @@ def cpu_baseline(sds, cfgs, runs, target_evals, scheduler):
     t_run, t_eval = statistics.median(totals), statistics.median(evals_t)
     per_image = t_run + (target_evals - n_evals) * t_eval
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "fp32 torch-CPU oracle, full-size model, BASELINE configs[0] end to end (B=1, 20 %s steps = %d CFG UNet evaluations, 512x384, EMASC on): "
+            "sample": "fp32 torch-CPU oracle, " + size + "-size model, BASELINE configs[0] end to end (B=1, 20 %s steps = %d CFG UNet evaluations, 512x384, EMASC on): "
                       "%d run(s), median %.1f s (min %.1f s), %.2f s per CFG evaluation; images/s at the metric's %d evaluations = 1 / (t_run + %d x t_eval)"
                       % (scheduler.upper(), n_evals, len(totals), t_run, min(totals), t_eval, target_evals, target_evals - n_evals),
             "config0_seconds_per_image": round(t_run, 2), "config0_images_per_s": round(1.0 / t_run, 5)}
@@ -280,7 +280,7 @@ def main():
     ecfg = C.emasc_for_vae(vcfg)
     cfgs = dict(unet=ucfg, vae=vcfg, emasc=ecfg)
     t_build = time.time()
-    want_cpu = (rank == 0 and world == 1 and not a.no_cpu_baseline and not a.roofline_only and a.size == "full")
+    want_cpu = (rank == 0 and world == 1 and not a.no_cpu_baseline and not a.roofline_only)
     if want_cpu:   # the CPU baseline needs the fp32 checkpoint on the host; otherwise stream it tensor by tensor
         sds = dict(unet=C.synth_state_dict(C.unet_shapes(ucfg), "unet."), vae=C.synth_state_dict(C.vae_shapes(vcfg), "vae."),
                    emasc=C.synth_state_dict(C.emasc_shapes(ecfg), "emasc."))
@@ -396,7 +396,7 @@ def main():
     cpu = None
     if want_cpu:
         try:
-            cpu = cpu_baseline(sds, cfgs, a.cpu_runs, evals, scheduler)
+            cpu = cpu_baseline(sds, cfgs, a.cpu_runs, evals, scheduler, a.size)
         except Exception as e:  # the baseline is reported, never required
             cpu = {"value": None, "unit": "images/s", "cores": host_cores(), "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0:
