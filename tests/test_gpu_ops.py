@@ -245,9 +245,12 @@ def test_gemm_f32_out():
 
 
 # --------------------------------------------------------------------------------------------------------------- norms
-@pytest.mark.parametrize("c0,c1,silu", [(64, 0, 1), (320, 0, 0), (128, 64, 1), (640, 320, 1)])
-def test_group_norm(lib, c0, c1, silu):
-    N, h, w, G = 2, 12, 10, 32
+@pytest.mark.parametrize("c0,c1,silu,hw", [(64, 0, 1, (12, 10)), (320, 0, 0, (12, 10)), (128, 64, 1, (12, 10)), (640, 320, 1, (12, 10)),
+                                           (320, 0, 1, (64, 48)), (1280, 1280, 1, (16, 12)), (128, 0, 1, (96, 64)), (256, 128, 0, (96, 64))])
+def test_group_norm(lib, c0, c1, silu, hw):
+    """partial rows -> per-channel scale / shift -> apply (+ SiLU, + add) over the virtual concat (c0 | c1), at UNet-like (64x48, 16x12)
+    and VAE-like (96x64, many partial rows) shapes"""
+    N, (h, w), G = 2, hw, 32
     a = _rand((N, c0, h, w), 31, 2.0) + 0.5
     b2 = _rand((N, c1, h, w), 32) if c1 else None
     gam, bet = _rand((c0 + c1,), 33, 0.1) + 1, _rand((c0 + c1,), 34, 0.1)
