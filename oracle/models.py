@@ -53,8 +53,12 @@ def attention(q, k, v, heads):
     q = q.view(n, T, heads, d).transpose(1, 2)
     k = k.view(n, k.shape[1], heads, d).transpose(1, 2)
     v = v.view(n, v.shape[1], heads, d).transpose(1, 2)
-    s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
-    o = torch.matmul(torch.softmax(s, dim=-1), v)
+    if n * heads * T * k.shape[2] > (1 << 28):      # 1024x768 self-attention: scores would take several GB; softmax is per query row, so
+        o = torch.cat([torch.matmul(torch.softmax(torch.matmul(q[:, :, i:i + 1024], k.transpose(-1, -2)) * (d ** -0.5), dim=-1), v)
+                       for i in range(0, T, 1024)], dim=2)                   # chunking the queries is the same arithmetic row by row
+    else:
+        s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
+        o = torch.matmul(torch.softmax(s, dim=-1), v)
     return o.transpose(1, 2).reshape(n, T, C)
 
 

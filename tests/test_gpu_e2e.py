@@ -103,3 +103,38 @@ def test_baseline_config_50_steps_vs_oracle(full, sched):
     assert res["final_latents_psnr_db"] >= 55.0 and res["noise_pred_psnr_db_min"] >= 50.0, res
     assert res["uint8_max_abs_diff"] <= 2, res
     assert eps_psnr[0] >= 55.0, eps_psnr[:3]                                       # first evaluation: no accumulated trajectory error yet
+
+
+def test_config4_resolution_short_run_vs_oracle(full):
+    """BASELINE configs[4] shapes (1024x768: 128x96 latents, 12 288-token self-attention, 12 288-token single-head VAE attention through the
+    wide flash kernel, 1024x768 EMASC skips) at B = 1 with 4 DDIM steps -- the full 100-step run costs the CPU oracle ~20 min, the shapes
+    are what this test is about.  Same contract as the 512x384 runs."""
+    import ladi_vton_amd as L
+    B, H, W, steps = 1, 1024, 768, 4
+    inp = P.synthetic_inputs(B, H, W, L=77, D=1024)
+    for k in ("prompt_embeds", "negative_prompt_embeds"):
+        inp[k] = inp[k].half().float()
+    trace = {}
+    t0 = time.time()
+    ref_img, ref_lat = P.tryon_pipeline(full["sd"]["unet"], full["ucfg"], full["sd"]["vae"], full["vcfg"], full["sd"]["emasc"], inp,
+                                        num_inference_steps=steps, guidance_scale=7.5, scheduler="ddim", trace=trace)
+    cpu_s = time.time() - t0
+    pipe = L.StableDiffusionTryOnePipeline(vae=full["mod"]["vae"], text_encoder=None, tokenizer=None, unet=full["mod"]["unet"],
+                                           scheduler=L.DDIMScheduler(), emasc=full["mod"]["emasc"], emasc_int_layers=[1, 2, 3, 4, 5])
+    pipe.trace_evals = steps
+    d = U.dev()
+    out = pipe(image=inp["image"].to(d), mask_image=inp["mask_image"].clone().to(d), pose_map=inp["pose_map"].to(d),
+               warped_cloth=inp["warped_cloth"].to(d), prompt_embeds=inp["prompt_embeds"].to(d),
+               negative_prompt_embeds=inp["negative_prompt_embeds"].to(d), height=H, width=W, num_inference_steps=steps,
+               guidance_scale=7.5, output_type="np", fused=True, use_graph=True,
+               noise=(inp["noise_cloth"], inp["noise_latents"], inp["noise_masked"]))
+    img = torch.from_numpy(out.images)
+    lat = pipe.last_latents.float().cpu()
+    tr = {k: v.cpu() for k, v in pipe.last_trace.items()}
+    eps_psnr = [round(U.psnr(tr["noise_pred"][i], trace["noise_pred"][i]), 2) for i in range(steps)]
+    u8a, u8b = (img * 255).round(), (ref_img * 255).round()
+    res = dict(evals=steps, image_psnr_db=round(U.psnr(img, ref_img, 1.0), 2), final_latents_psnr_db=round(U.psnr(lat, ref_lat), 2),
+               uint8_max_abs_diff=int((u8a - u8b).abs().max()), noise_pred_psnr_db_per_eval=eps_psnr, cpu_oracle_seconds=round(cpu_s, 1))
+    _record("tryon_1024x768_4_ddim_B1", res)
+    assert img.shape == ref_img.shape == (B, H, W, 3)
+    assert res["image_psnr_db"] >= 50.0 and res["final_latents_psnr_db"] >= 55.0 and min(eps_psnr) >= 50.0, res
