@@ -381,7 +381,13 @@ def main():
             d = sym[dom]
             ach = d["flop"] / d["ms"] / 1e9
             extra = ["--config", str(a.config), "--batch", str(B), "--height", str(H), "--width", str(W), "--size", a.size]
-            traffic, note = (traffic_measured(dom, extra) if a.measure_traffic and not a.roofline_only else traffic_committed(dom))
+            default_workload = (a.config == 1 and B == CONFIGS[1]["batch"] and (H, W) == (CONFIGS[1]["H"], CONFIGS[1]["W"]) and a.size == "full")
+            if a.measure_traffic and not a.roofline_only:
+                traffic, note = traffic_measured(dom, extra)
+            elif default_workload:
+                traffic, note = traffic_committed(dom)
+            else:      # the committed PMC passes were taken on the default workload: another launch population, not comparable
+                traffic, note = None, "committed PMC passes cover the default workload (config 1) only; use --measure-traffic"
             fwd_flop = UNET_FLOP_PER_SAMPLE_64x48 * n * (h * w / 3072.0) if a.size == "full" and (h, w) == (64, 48) else None
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4),
                         "traffic": traffic, "traffic_note": note, "kernel": dom, "tile_cfgs": d["cfgs"],
