@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 
 # algorithmic work (SURVEY.md §8d / BASELINE.md §2), 2*MAC FLOPs
 UNET_FLOP_PER_SAMPLE_64x48 = 581.70e9
-TRYON_FLOP_PER_IMAGE = {("ddim", 50, 512): 62.16e12, ("pndm", 50, 512): 63.32e12, ("ddim", 100, 1024): 644.9e12}
+TRYON_FLOP_PER_IMAGE = {("ddim", 50, 512): 62.16e12, ("lms", 50, 512): 62.16e12, ("pndm", 50, 512): 63.32e12, ("ddim", 100, 1024): 644.9e12}
 PEAK_F16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
 CONFIGS = {   # BASELINE.json `configs` index -> (batch per GPU, steps, scheduler, H, W, producers)
     1: dict(batch=8, steps=50, scheduler="pndm", H=512, W=384, producers=False,
