@@ -49,18 +49,13 @@ CONFIGS = {   # BASELINE.json `configs` index -> (batch per GPU, steps, schedule
     4: dict(batch=8, steps=100, scheduler="ddim", H=1024, W=768, producers=False,
             name="BASELINE configs[4]: DressCode-like 1024x768, batch 64 over 8 GPUs = 8 per GPU"),
 }
-# tile configuration id (csrc/igemm.hip kCfg) -> kernel symbol as rocprofv3 prints it; split-K variants launch the same symbol
-SYMBOL = {1: "igemm_kernel<2, 2, 2, 4, 32, 3>", 2: "igemm_kernel<2, 2, 5, 2, 32, 2>", 3: "igemm_kernel<2, 2, 2, 2, 32, 3>",
-          4: "igemm_kernel<2, 2, 2, 1, 32, 3>", 5: "igemm_kernel<2, 2, 1, 1, 32, 3>", 6: "igemm_kernel<2, 2, 4, 2, 32, 3>",
-          7: "igemm_kernel<2, 2, 2, 2, 64, 2>", 8: "igemm_kernel<2, 2, 2, 4, 64, 2>", 9: "igemm_kernel<2, 2, 2, 1, 64, 3>",
-          10: "igemm_kernel<2, 2, 5, 2, 64, 2>", 16: "igemm_kernel<2, 2, 1, 1, 32, 4>", 17: "igemm_kernel<2, 2, 2, 1, 32, 4>",
-          18: "igemm_kernel<2, 2, 2, 2, 32, 4>", 19: "igemm_kernel<2, 4, 2, 2, 32, 3>", 20: "igemm_kernel<4, 2, 2, 2, 32, 3>",
-          21: "igemm_kernel<2, 4, 4, 2, 32, 3>", 22: "igemm_kernel<2, 4, 5, 2, 64, 2>", 32: "igemm8_kernel<5, 2, 0>",
-          33: "igemm8_kernel<4, 2, 0>"}
-SYMBOL.update({11: SYMBOL[9], 12: SYMBOL[9], 13: SYMBOL[9], 14: SYMBOL[7], 15: SYMBOL[7], 28: SYMBOL[20], 29: SYMBOL[20], 30: SYMBOL[19],
-               31: SYMBOL[19], 34: SYMBOL[32], 35: SYMBOL[32], 36: SYMBOL[33], 37: SYMBOL[33], 38: SYMBOL[33]})
-SYMBOL.update({c: "linear_xs_kernel" for c in range(23, 28)})
-NCFG = 38
+
+
+def igemm_symbols(lib):
+    """tile configuration id (csrc/igemm.hip kCfg) -> kernel symbol as rocprofv3 prints it; split-K variants launch the symbol of their
+    base tile.  The table lives in the library (ladi_igemm_cfg_symbol_name), so a new tile shape needs no edit here."""
+    n = lib.ladi_igemm_cfg_count()
+    return n, {c: lib.ladi_igemm_cfg_symbol_name(c).decode() for c in range(1, n + 1)}
 
 
 def parse():
@@ -368,6 +363,7 @@ def main():
         lib.ladi_profile_igemm_enable(1)
         unet.time_forward(n, h, w, a.roofline_iters)   # 1 warm-up + roofline_iters timed forwards, all recorded
         lib.ladi_profile_igemm_enable(0)
+        NCFG, SYMBOL = igemm_symbols(lib)
         prof = (ctypes.c_double * (3 * (NCFG + 1)))()
         lib.ladi_profile_igemm_collect(prof, 3 * (NCFG + 1))
         sym = {}

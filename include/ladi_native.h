@@ -236,7 +236,7 @@ int ladi_tryon_stage_ms(ladi_tryon* t, float* out3);
 int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* avg_ms, void* stream);
 
 /* per-launch HIP-event timing of the implicit-GEMM kernel family (the dominant kernel): enable, run any entry point,
- * then collect: out[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP = 2*P*Q*K, launches} for tile configuration cfg = 1..31
+ * then collect: out[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP = 2*P*Q*K, launches} for tile configuration cfg = 1..ladi_igemm_cfg_count()
  * (igemm tile shapes, split-K variants, the X-stationary linear kernel; table in csrc/igemm.hip), index 0 = all; entries beyond
  * n_out are dropped. collect() synchronises and clears the records. */
 /* measured tile-shape selection (default on): the first launch of a new problem shape outside a stream capture times the
@@ -244,6 +244,10 @@ int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* 
 void ladi_igemm_set_autotune(int on);
 void ladi_profile_igemm_enable(int on);
 int ladi_profile_igemm_collect(double* out, int n_out);
+/* number of tile configurations (valid ids 1..count) and the kernel symbol configuration `cfg` launches, as rocprofv3 names it
+ * (split-K variants share the symbol of their base tile); "" for an unknown id.  The string is owned by the library. */
+int ladi_igemm_cfg_count(void);
+const char* ladi_igemm_cfg_symbol_name(int cfg);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Op-level entry points (kernel parity tests; NHWC fp16 device tensors)

@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libladi_native.so")
-SOURCES = ["igemm.hip", "igemm8.hip", "linear_xs.hip", "norm.hip", "attention.hip", "elementwise.hip", "runtime_core.cpp", "runtime_unet.cpp",
+SOURCES = ["igemm.hip"] + ["igemm_inst_%s.hip" % g for g in "abcdefghi"] + ["igemm8.hip", "linear_xs.hip", "norm.hip", "attention.hip", "elementwise.hip", "runtime_core.cpp", "runtime_unet.cpp",
            "runtime_vae.cpp", "runtime_text.cpp", "runtime_vision.cpp", "runtime_refine.cpp", "runtime_tps.cpp", "runtime_tryon.cpp", "capi.cpp"]
-HEADERS = ["common.h", "kernels.h", "igemm_common.h", "runtime.h", os.path.join("..", "..", "include", "ladi_native.h")]
+HEADERS = ["common.h", "kernels.h", "igemm_common.h", "igemm_kernel.h", "igemm_tiles.h", "runtime.h", os.path.join("..", "..", "include", "ladi_native.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function"]
 
 
@@ -36,11 +36,37 @@ def _digest():
 
 
 def build(force=False, verbose=True):
+    """Compile what changed and link.  Safe under `torchrun` (N ranks importing the package at once): the whole build runs under an
+    exclusive flock on csrc/_obj/.lock, objects / library / stamps are written to temporary names and os.replace()d into place, so a
+    concurrent rank either waits and then finds everything up to date, or dlopens a complete library -- never a half-written one."""
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
     stamp = os.path.join(OBJ, "stamp")
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+
+    def fresh():
+        return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig
+
+    if not force and fresh():
         return LIB
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():          # another process built it while this one waited for the lock
+                return LIB
+            return _build_locked(force, verbose, stamp, dig)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _write_atomic(path, text):
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "w") as fh:
+        fh.write(text)
+    os.replace(tmp, path)
+
+
+def _build_locked(force, verbose, stamp, dig):
     hipcc = _hipcc()
 
     hdr = hashlib.sha256()
@@ -58,24 +84,26 @@ def build(force=False, verbose=True):
         ostamp = obj + ".stamp"
         if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == h.hexdigest():
             return obj
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        tmp = "%s.tmp%d.o" % (obj, os.getpid())
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             sys.stderr.write(r.stderr)
-        with open(ostamp, "w") as fh:
-            fh.write(h.hexdigest())
+        os.replace(tmp, obj)
+        _write_atomic(ostamp, h.hexdigest())
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    tmp_lib = "%s.tmp%d" % (LIB, os.getpid())
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    with open(stamp, "w") as fh:
-        fh.write(dig)
+    os.replace(tmp_lib, LIB)
+    _write_atomic(stamp, dig)
     return LIB
 
 

@@ -35,180 +35,13 @@
 #include <dlfcn.h>
 
 int ladi_igemm_num_cfgs();
+#include "igemm_tiles.h"
+// one launcher per ring-kernel tile shape, defined in igemm_inst_*.hip (igemm_kernel.h)
+#define X(base, WQ, WP, TQ, TP, BK, NST, OCC, ILV) int ladi_igemm_launch_base_##base(IGemmArgs a, int batch, hipStream_t st);
+LADI_IGEMM_TILES_ALL(X)
+#undef X
 
 namespace {
-
-template <int WQ, int WP, int TQ, int TP, int BK, int NST>
-__global__ __launch_bounds__(64 * WQ * WP, 2) void igemm_kernel(const IGemmArgs a) {
-    constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
-    constexpr int CPR = BK / 8;          // 16-byte chunks per LDS row
-    constexpr int NT = 64 * WQ * WP;      // threads per workgroup (4 or 8 waves)
-    constexpr int RPP = NT / CPR;        // tile rows covered by one pass of the workgroup
-    constexpr int RQ = BQ / RPP, RP = BP / RPP;
-    constexpr int STAGE = (BQ + BP) * BK;  // halves per stage
-    constexpr int NKK = BK / 16;
-    static_assert(NST >= 2 && NST <= 4, "ring depth");
-    static_assert(BQ % RPP == 0 && BP % RPP == 0, "tile rows must be a multiple of the rows per pass");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    h16* smem = reinterpret_cast<h16*>(smem_raw);
-
-    const int tid = threadIdx.x;
-    const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
-    int qt, pt;
-    {
-        const int b = blockIdx.x;
-        if (a.tile_map == 1) {          // pixel tiles split across the 8 XCDs, q fastest inside an XCD
-            const int npx = (np + 7) >> 3, xcd = b & 7, loc = b >> 3;
-            pt = xcd * npx + loc / nq; qt = loc % nq;
-            if (pt >= np) return;
-        } else if (a.tile_map == 2) {   // channel tiles split across the XCDs, p fastest inside an XCD
-            const int nqx = (nq + 7) >> 3, xcd = b & 7, loc = b >> 3;
-            qt = xcd * nqx + loc / np; pt = loc % np;
-            if (qt >= nq) return;
-        } else { qt = b % nq; pt = b / nq; }
-    }
-    const int q0 = qt * BQ, p0 = pt * BP;
-    const int z = blockIdx.z;
-
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int cphys = tid % CPR;          // physical chunk this lane's DMA lands in
-    const int r0 = tid / CPR;             // row within a pass
-    const int clog = (BK == 64) ? (cphys ^ ((r0 >> 1) & 7)) : (cphys ^ ((r0 >> 2) & 3));  // logical chunk it must fetch
-
-    // ---- buffer descriptors (wave-uniform); activation descriptors are rebased to the tile's first sample so that
-    //      32-bit byte offsets never overflow
-    const int HoWo = a.Ho * a.Wo;
-    const int HsWs = a.Hs * a.Ws;
-    const int n_first = p0 / HoWo;
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<h16*>(a.src0 + (a.splitk > 1 ? 0 : (size_t)z * a.bs_src0) + (size_t)n_first * HsWs * a.ld0), 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<h16*>(a.src1 ? a.src1 + (size_t)n_first * HsWs * a.ld1 : a.src0), 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<h16*>(a.W + (a.splitk > 1 ? 0 : (size_t)z * a.bs_w)), 0, 0x7FFFFFFF, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-
-    // ---- per-thread pixel-row decode (constant over the K loop)
-    const int Hlog = a.ups ? 2 * a.Hs : a.Hs;
-    const int Wlog = a.ups ? 2 * a.Ws : a.Ws;
-    int nb[RP], iy0[RP], ix0[RP];
-#pragma unroll
-    for (int i = 0; i < RP; ++i) {
-        const int p = p0 + r0 + RPP * i;
-        const bool ok = p < a.P;
-        const int pp = ok ? p : 0;
-        const int n = pp / HoWo;
-        const int rem = pp - n * HoWo;
-        const int oy = rem / a.Wo;
-        const int ox = rem - oy * a.Wo;
-        iy0[i] = ok ? (oy * a.stride - a.pad) : -100000;  // invalid rows fail the bounds test
-        ix0[i] = ox * a.stride - a.pad;
-        nb[i] = (n - n_first) * HsWs;
-    }
-    const int Ct = a.C0 + a.C1;
-    const int ldw = a.ldw ? a.ldw : a.K;
-    unsigned wbase[RQ];
-#pragma unroll
-    for (int i = 0; i < RQ; ++i) {
-        const int q = q0 + r0 + RPP * i;
-        wbase[i] = (q < a.Q) ? (unsigned)(((size_t)q * ldw + clog * 8) * 2) : OOB;
-    }
-
-    // split-K: grid.z slices the K loop (a.splitk > 1); each slice writes an fp32 partial tile (see splitk_reduce_kernel)
-    // K-loop order: channel chunk OUTER, tap INNER.  The 9 taps of one channel chunk read overlapping input rows in consecutive
-    // steps, so all but the first hit in L2; tap-outer order re-streamed the whole pixel tile once per tap with a reuse distance
-    // (a full channel sweep x 32 co-resident workgroups per XCD) beyond the 4 MB L2.  Weights stay tap-major in memory: only the
-    // sequence of k offsets changes.
-    int nk = a.K / BK;
-    const int ntap = a.ksize * a.ksize;
-    int tap = 0, cb = 0;  // (tap, channel base) of the NEXT stage to issue
-    if (a.splitk > 1) {
-        const int sps = (nk + a.splitk - 1) / a.splitk;
-        const int start = z * sps;
-        nk = max(0, min(sps, nk - start));
-        cb = (start / ntap) * BK; tap = start - (start / ntap) * ntap;
-    }
-    int tdy = tap / a.ksize, tdx = tap - (tap / a.ksize) * a.ksize;   // window offset of `tap`, advanced incrementally (no per-step division)
-
-    auto issue = [&](int stage) {
-        const int dy = tdy, dx = tdx;
-        const bool s0 = cb < a.C0;
-        const __amdgpu_buffer_rsrc_t rs = s0 ? rs0 : rs1;
-        const int ld = s0 ? a.ld0 : a.ld1;
-        const int c = (s0 ? cb : cb - a.C0) + clog * 8;
-        const int k0 = tap * Ct + cb;
-        char* sbase = smem_raw + (size_t)stage * (STAGE * 2) + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < RQ; ++i) {
-            const unsigned vo = (wbase[i] == OOB) ? OOB : wbase[i] + (unsigned)(k0 * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(sbase + i * (RPP * BK * 2)), 16, vo, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < RP; ++i) {
-            int iy = iy0[i] + dy, ix = ix0[i] + dx;
-            const bool ok = ((unsigned)iy < (unsigned)Hlog) && ((unsigned)ix < (unsigned)Wlog);
-            if (a.ups) { iy >>= 1; ix >>= 1; }
-            const unsigned vo = ok ? (unsigned)(((nb[i] + iy * a.Ws + ix) * ld + c) * 2) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sbase + (BQ * BK * 2) + i * (RPP * BK * 2)), 16, vo, 0, 0, 0);
-        }
-        if (++tdx == a.ksize) { tdx = 0; ++tdy; }
-        if (++tap == ntap) { tap = 0; tdy = 0; tdx = 0; cb += BK; }
-    };
-
-    const int wq = wave / WP, wp = wave % WP;
-    const int l31 = lane & 31, hh = lane >> 5;
-
-    f32x16 acc[TQ][TP];
-#pragma unroll
-    for (int i = 0; i < TQ; ++i)
-#pragma unroll
-        for (int j = 0; j < TP; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- prologue: NST-1 stages in flight
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < nk) issue(s);
-
-    constexpr int L = RQ + RP;  // DMA instructions per stage per wave
-    for (int kt = 0; kt < nk; ++kt) {
-        // my part of stage kt has landed (later stages may stay in flight), then rendezvous: every wave's part of stage kt is
-        // visible and every wave has finished reading the ring slot that is refilled next
-        {
-            const int later = min(NST - 2, nk - 1 - kt);   // stages issued after stage kt that may stay in flight
-            if (NST >= 4 && later >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * L) : "memory");
-            else if (NST >= 3 && later >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(L) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-        if (kt + NST - 1 < nk) issue((kt + NST - 1) % NST);
-        const h16* sW = smem + (kt % NST) * STAGE;
-        const h16* sX = sW + BQ * BK;
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            const int chunk = kk * 2 + hh;
-            h16x8 af[TQ], bf[TP];
-#pragma unroll
-            for (int i = 0; i < TQ; ++i) {
-                const int r = (wq * TQ + i) * 32 + l31;
-                af[i] = *reinterpret_cast<const h16x8*>(sW + swz<BK>(r, chunk));
-            }
-#pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                const int r = (wp * TP + j) * 32 + l31;
-                bf[j] = *reinterpret_cast<const h16x8*>(sX + swz<BK>(r, chunk));
-            }
-#pragma unroll
-            for (int i = 0; i < TQ; ++i)
-#pragma unroll
-                for (int j = 0; j < TP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    igemm_epilogue<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane);
-}
 
 // ------------------------------------------------------------------------------------------------
 // split-K second pass: out = epilogue(sum_z part[z]) for problems with few output tiles and a deep K loop (the 8x6 level of the
@@ -274,78 +107,118 @@ bool ensure_ws(size_t bytes, hipStream_t st) {
     return true;
 }
 
-struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; int base; int split; };
+struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; int base; int split; int bk; bool tune; };
 // tile configurations (0 = choose: measured per shape when autotuning is on, else the cost model below).
-// {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K}
-constexpr int NCFG = 38;
+// {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K,
+//  K step, offered to the tuner}
+constexpr int NCFG = 61;
 const CfgInfo kCfg[NCFG + 1] = {
-    {0, 0, 0, false, 0.f, 0, 0, 1},
-    {128, 256, 2, true, 0.80f, 4, 1, 1},   // 1: <2,2,2,4> BK32 NST3
-    {320, 128, 2, false, 1.00f, 2, 2, 1},  // 2: <2,2,5,2> BK32 NST2 (Cout = 320 layers, no padding waste)
-    {128, 128, 3, true, 1.00f, 2, 3, 1},   // 3: <2,2,2,2> BK32 NST3
-    {128, 64, 4, true, 0.80f, 1, 4, 1},    // 4: <2,2,2,1> BK32 NST3
-    {64, 64, 6, false, 0.60f, 1, 5, 1},    // 5: <2,2,1,1> BK32 NST3
-    {256, 128, 2, true, 0.85f, 2, 6, 1},   // 6: <2,2,4,2> BK32 NST3
-    {128, 128, 2, true, 0.00f, 2, 7, 1},   // 7: <2,2,2,2> BK64 NST2   (eff 0: picked by measurement only, not by the fallback cost model)
-    {128, 256, 1, true, 0.00f, 4, 8, 1},   // 8: <2,2,2,4> BK64 NST2
-    {128, 64, 2, true, 0.00f, 1, 9, 1},    // 9: <2,2,2,1> BK64 NST3
-    {320, 128, 1, false, 0.00f, 2, 10, 1},  // 10: <2,2,5,2> BK64 NST2
-    {128, 64, 2, false, 0.00f, 1, 9, 2},    // 11: cfg 9 + split-K 2
-    {128, 64, 2, false, 0.00f, 1, 9, 4},    // 12: cfg 9 + split-K 4
-    {128, 64, 2, false, 0.00f, 1, 9, 8},    // 13: cfg 9 + split-K 8
-    {128, 128, 2, false, 0.00f, 2, 7, 2},   // 14: cfg 7 + split-K 2
-    {128, 128, 2, false, 0.00f, 2, 7, 4},   // 15: cfg 7 + split-K 4
-    {64, 64, 5, false, 0.00f, 1, 16, 1},    // 16: <2,2,1,1> BK32 NST4 (deeper prefetch for shallow-K, latency-bound GEMMs)
-    {128, 64, 3, true, 0.00f, 1, 17, 1},    // 17: <2,2,2,1> BK32 NST4
-    {128, 128, 2, true, 0.00f, 2, 18, 1},   // 18: <2,2,2,2> BK32 NST4
-    {128, 256, 2, true, 0.00f, 2, 19, 1},   // 19: <2,4,2,2> BK32 NST3   8 waves (512 threads)
-    {256, 128, 2, true, 0.00f, 2, 20, 1},   // 20: <4,2,2,2> BK32 NST3   8 waves
-    {256, 256, 2, true, 0.00f, 2, 21, 1},   // 21: <2,4,4,2> BK32 NST3   8 waves, 96 KB LDS (1 workgroup / CU; listed as 2 so the tuner tries it)
-    {320, 256, 2, false, 0.00f, 2, 22, 1},  // 22: <2,4,5,2> BK64 NST2   8 waves, 144 KB LDS
+    {0, 0, 0, false, 0.f, 0, 0, 1, 0, false},
+    {128, 256, 2, true, 0.80f, 4, 1, 1, 32, true},   // 1: <2,2,2,4> BK32 NST3
+    {320, 128, 2, false, 1.00f, 2, 2, 1, 32, true},  // 2: <2,2,5,2> BK32 NST2 (Cout = 320 layers, no padding waste)
+    {128, 128, 3, true, 1.00f, 2, 3, 1, 32, true},   // 3: <2,2,2,2> BK32 NST3
+    {128, 64, 4, true, 0.80f, 1, 4, 1, 32, true},    // 4: <2,2,2,1> BK32 NST3
+    {64, 64, 6, false, 0.60f, 1, 5, 1, 32, true},    // 5: <2,2,1,1> BK32 NST3
+    {256, 128, 2, true, 0.85f, 2, 6, 1, 32, true},   // 6: <2,2,4,2> BK32 NST3
+    {128, 128, 2, true, 0.00f, 2, 7, 1, 64, true},   // 7: <2,2,2,2> BK64 NST2   (eff 0: picked by measurement only, not by the fallback cost model)
+    {128, 256, 1, true, 0.00f, 4, 8, 1, 64, false},  // 8: <2,2,2,4> BK64 NST2   (never won a shape: not offered to the tuner)
+    {128, 64, 2, true, 0.00f, 1, 9, 1, 64, true},    // 9: <2,2,2,1> BK64 NST3
+    {320, 128, 1, false, 0.00f, 2, 10, 1, 64, false},  // 10: <2,2,5,2> BK64 NST2
+    {128, 64, 2, false, 0.00f, 1, 9, 2, 64, true},    // 11: cfg 9 + split-K 2
+    {128, 64, 2, false, 0.00f, 1, 9, 4, 64, true},    // 12: cfg 9 + split-K 4
+    {128, 64, 2, false, 0.00f, 1, 9, 8, 64, true},    // 13: cfg 9 + split-K 8
+    {128, 128, 2, false, 0.00f, 2, 7, 2, 64, true},   // 14: cfg 7 + split-K 2
+    {128, 128, 2, false, 0.00f, 2, 7, 4, 64, true},   // 15: cfg 7 + split-K 4
+    {64, 64, 5, false, 0.00f, 1, 16, 1, 32, true},    // 16: <2,2,1,1> BK32 NST4 (deeper prefetch for shallow-K, latency-bound GEMMs)
+    {128, 64, 3, true, 0.00f, 1, 17, 1, 32, true},    // 17: <2,2,2,1> BK32 NST4
+    {128, 128, 2, true, 0.00f, 2, 18, 1, 32, true},   // 18: <2,2,2,2> BK32 NST4
+    {128, 256, 2, true, 0.00f, 2, 19, 1, 32, true},   // 19: <2,4,2,2> BK32 NST3   8 waves (512 threads)
+    {256, 128, 2, true, 0.00f, 2, 20, 1, 32, true},   // 20: <4,2,2,2> BK32 NST3   8 waves
+    {256, 256, 1, true, 0.00f, 2, 21, 1, 32, true},   // 21: <2,4,4,2> BK32 NST3   8 waves, 96 KB LDS
+    {320, 256, 1, false, 0.00f, 2, 22, 1, 64, true},  // 22: <2,4,5,2> BK64 NST2   8 waves, 144 KB LDS
     // 23..27: X-stationary linear kernel (linear_xs.hip; K = 320 / 640 token-wise projections).  bq field = channel slices
     // over gridDim.y, tp field = 32-pixel blocks per wave
-    {1, 256, 2, false, 0.00f, 2, 23, 1},    // 23: 64 pixels / wave, 1 channel slice
-    {2, 256, 2, false, 0.00f, 2, 23, 1},    // 24: 64 pixels / wave, 2 channel slices
-    {1, 128, 2, true, 0.00f, 1, 23, 1},     // 25: 32 pixels / wave, 1 channel slice   (25..27 also: residual, GEGLU)
-    {2, 128, 2, true, 0.00f, 1, 23, 1},     // 26: 32 pixels / wave, 2 channel slices
-    {5, 128, 2, true, 0.00f, 1, 23, 1},     // 27: 32 pixels / wave, 5 channel slices
+    {1, 256, 2, false, 0.00f, 2, 23, 1, 0, true},    // 23: 64 pixels / wave, 1 channel slice
+    {2, 256, 2, false, 0.00f, 2, 23, 1, 0, true},    // 24: 64 pixels / wave, 2 channel slices
+    {1, 128, 2, true, 0.00f, 1, 23, 1, 0, true},     // 25: 32 pixels / wave, 1 channel slice   (25..27 also: residual, GEGLU)
+    {2, 128, 2, true, 0.00f, 1, 23, 1, 0, true},     // 26: 32 pixels / wave, 2 channel slices
+    {5, 128, 2, true, 0.00f, 1, 23, 1, 0, true},     // 27: 32 pixels / wave, 5 channel slices
     // 28..31: 8-wave tiles + split-K for the deep-K, few-pixel levels (half the staging bytes per MAC of the 128x64 tile)
-    {256, 128, 2, false, 0.00f, 2, 20, 4},  // 28: cfg 20 + split-K 4
-    {256, 128, 2, false, 0.00f, 2, 20, 8},  // 29: cfg 20 + split-K 8
-    {128, 256, 2, false, 0.00f, 2, 19, 4},  // 30: cfg 19 + split-K 4
-    {128, 256, 2, false, 0.00f, 2, 19, 8},  // 31: cfg 19 + split-K 8
+    {256, 128, 2, false, 0.00f, 2, 20, 4, 32, true},  // 28: cfg 20 + split-K 4
+    {256, 128, 2, false, 0.00f, 2, 20, 8, 32, true},  // 29: cfg 20 + split-K 8
+    {128, 256, 2, false, 0.00f, 2, 19, 4, 32, true},  // 30: cfg 19 + split-K 4
+    {128, 256, 2, false, 0.00f, 2, 19, 8, 32, true},  // 31: cfg 19 + split-K 8
     // 32..38: igemm8_kernel, the phase-staggered 8-wave large-tile pipeline (BK = 64, one workgroup per CU, 2 K-tile buffers)
-    {320, 256, 2, false, 0.00f, 2, 32, 1},  // 32: igemm8<5,2>  (Cout = 320 / 640 / 960 / 1280 layers without padding waste)
-    {256, 256, 2, true, 0.00f, 2, 33, 1},   // 33: igemm8<4,2>
-    {320, 256, 2, false, 0.00f, 2, 32, 2},  // 34: cfg 32 + split-K 2
-    {320, 256, 2, false, 0.00f, 2, 32, 4},  // 35: cfg 32 + split-K 4
-    {256, 256, 2, false, 0.00f, 2, 33, 2},  // 36: cfg 33 + split-K 2
-    {256, 256, 2, false, 0.00f, 2, 33, 4},  // 37: cfg 33 + split-K 4
-    {256, 256, 2, false, 0.00f, 2, 33, 8},  // 38: cfg 33 + split-K 8
+    {320, 256, 1, false, 0.00f, 2, 32, 1, 64, true},  // 32: igemm8<5,2>  (Cout = 320 / 640 / 960 / 1280 layers without padding waste)
+    {256, 256, 1, true, 0.00f, 2, 33, 1, 64, true},   // 33: igemm8<4,2>
+    {320, 256, 1, false, 0.00f, 2, 32, 2, 64, true},  // 34: cfg 32 + split-K 2
+    {320, 256, 1, false, 0.00f, 2, 32, 4, 64, true},  // 35: cfg 32 + split-K 4
+    {256, 256, 1, false, 0.00f, 2, 33, 2, 64, true},  // 36: cfg 33 + split-K 2
+    {256, 256, 1, false, 0.00f, 2, 33, 4, 64, true},  // 37: cfg 33 + split-K 4
+    {256, 256, 1, false, 0.00f, 2, 33, 8, 64, true},  // 38: cfg 33 + split-K 8
+    // 39..53 (round 3): 4-wave tiles with ONE workgroup per CU (one wave per SIMD, up to 240 accumulator registers): grids that fill the
+    // 256 CUs at batch 8 and rings that keep 64-128 KB in flight per CU; DMA issue interleaved with the MFMA groups
+    {320, 192, 1, false, 0.00f, 3, 39, 1, 64, true},  // 39: <2,2,5,3> BK64 NST2 interleaved: 256 tiles on the 49 152-pixel level
+    {320, 192, 1, false, 0.00f, 3, 40, 1, 32, true},  // 40: <2,2,5,3> BK32 NST4 interleaved (every stage issued 3 K steps ahead)
+    {256, 256, 1, true, 0.00f, 4, 41, 1, 64, true},   // 41: <2,2,4,4> BK64 NST2
+    {128, 128, 1, true, 0.00f, 2, 42, 1, 64, true},   // 42: <2,2,2,2> BK64 NST4 (128 KB ring)
+    {128, 256, 1, true, 0.00f, 4, 43, 1, 64, true},   // 43: <2,2,2,4> BK64 NST3 (144 KB ring)
+    {128, 64, 1, true, 0.00f, 1, 44, 1, 64, true},    // 44: <2,2,2,1> BK64 NST5 (120 KB ring)
+    {256, 192, 1, true, 0.00f, 3, 45, 1, 64, true},   // 45: <2,2,4,3> BK64 NST2
+    {320, 192, 1, false, 0.00f, 3, 39, 2, 64, true},  // 46: cfg 39 + split-K 2
+    {128, 128, 2, true, 0.00f, 2, 47, 1, 64, true},   // 47: cfg 7 with interleaved DMA issue
+    {128, 64, 2, true, 0.00f, 1, 48, 1, 64, true},    // 48: cfg 9 with interleaved DMA issue
+    {256, 256, 1, false, 0.00f, 4, 41, 4, 64, true},  // 49: cfg 41 + split-K 4
+    {256, 256, 1, false, 0.00f, 4, 41, 2, 64, true},  // 50: cfg 41 + split-K 2
+    {256, 192, 1, false, 0.00f, 3, 45, 3, 64, true},  // 51: cfg 45 + split-K 3
+    {128, 128, 2, false, 0.00f, 2, 47, 2, 64, true},  // 52: cfg 47 + split-K 2
+    {128, 64, 2, false, 0.00f, 1, 48, 4, 64, true},   // 53: cfg 48 + split-K 4
+    // 54..61 (round 3): more shapes of the phase-staggered 8-wave pipeline, igemm8<TQ,TP> = (64 TQ) x (128 TP)
+    {128, 256, 1, true, 0.00f, 2, 54, 1, 64, true},   // 54: igemm8<2,2>
+    {256, 128, 1, true, 0.00f, 1, 55, 1, 64, true},   // 55: igemm8<4,1>
+    {128, 128, 2, true, 0.00f, 1, 56, 1, 64, true},   // 56: igemm8<2,1> (64 KB of LDS: two workgroups = 16 waves per CU)
+    {320, 128, 1, false, 0.00f, 1, 57, 1, 64, true},  // 57: igemm8<5,1>
+    {192, 256, 1, false, 0.00f, 2, 58, 1, 64, true},  // 58: igemm8<3,2>
+    {128, 256, 1, false, 0.00f, 2, 54, 2, 64, true},  // 59: cfg 54 + split-K 2
+    {256, 128, 1, false, 0.00f, 1, 55, 2, 64, true},  // 60: cfg 55 + split-K 2
+    {320, 128, 1, false, 0.00f, 1, 57, 2, 64, true},  // 61: cfg 57 + split-K 2
 };
 
-template <int WQ, int WP, int TQ, int TP, int BK, int NST>
-int launch_cfg(IGemmArgs a, int batch, hipStream_t st) {
-    constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
-    constexpr int RING = NST * (BQ + BP) * BK * (int)sizeof(h16), EPI = igemm_epilogue_lds_bytes<WQ, WP, TQ>();
-    constexpr int SMEM = RING > EPI ? RING : EPI;
-    static bool attr_set = false;
-    auto kfn = igemm_kernel<WQ, WP, TQ, TP, BK, NST>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
-            return -10;
-        attr_set = true;
+// rocprofv3's name of the kernel a configuration launches (bench.py groups its per-launch timings by symbol)
+std::string cfg_symbol(int c) {
+    const int b = kCfg[c].base;
+    if (b == 23) return "linear_xs_kernel";
+    switch (b) {
+        case 32: return "igemm8_kernel<5, 2, 0>";
+        case 33: return "igemm8_kernel<4, 2, 0>";
+        case 54: return "igemm8_kernel<2, 2, 0>";
+        case 55: return "igemm8_kernel<4, 1, 0>";
+        case 56: return "igemm8_kernel<2, 1, 0>";
+        case 57: return "igemm8_kernel<5, 1, 0>";
+        case 58: return "igemm8_kernel<3, 2, 0>";
+#define X(base, WQ, WP, TQ, TP, BK, NST, OCC, ILV) \
+        case base: return "igemm_kernel<" #WQ ", " #WP ", " #TQ ", " #TP ", " #BK ", " #NST ", " #OCC ", " #ILV ">";
+        LADI_IGEMM_TILES_ALL(X)
+#undef X
+        default: return "?";
     }
-    const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
-    int blocks = nq * np;
-    a.tile_map = 0;
-    if (batch == 1 || a.splitk > 1) {
-        if (np >= 16) { a.tile_map = 1; blocks = 8 * ((np + 7) / 8) * nq; }
-        else if (nq >= 16) { a.tile_map = 2; blocks = 8 * ((nq + 7) / 8) * np; }
+}
+
+int launch_base(int cfg, const IGemmArgs& a, int batch, hipStream_t st) {
+    switch (kCfg[cfg].base) {
+#define X(base, WQ, WP, TQ, TP, BK, NST, OCC, ILV) case base: return ladi_igemm_launch_base_##base(a, batch, st);
+        LADI_IGEMM_TILES_ALL(X)
+#undef X
+        case 23: return ladi_launch_linear_xs(a, kCfg[cfg].tp, kCfg[cfg].bq, st);
+        case 32: return ladi_launch_igemm8(a, 5, 2, batch, st);
+        case 33: return ladi_launch_igemm8(a, 4, 2, batch, st);
+        case 54: return ladi_launch_igemm8(a, 2, 2, batch, st);
+        case 55: return ladi_launch_igemm8(a, 4, 1, batch, st);
+        case 56: return ladi_launch_igemm8(a, 2, 1, batch, st);
+        case 57: return ladi_launch_igemm8(a, 5, 1, batch, st);
+        case 58: return ladi_launch_igemm8(a, 3, 2, batch, st);
+        default: return -7;
     }
-    dim3 grid((unsigned)blocks, 1, (unsigned)batch);
-    hipLaunchKernelGGL(kfn, grid, dim3(64 * WQ * WP), SMEM, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 
 struct ProfRec { hipEvent_t e0, e1; int cfg; double flops; int P, Q, K, ks; };
@@ -410,11 +283,40 @@ void tune_cache_append(const TuneKey& k, int cfg) {
 }  // namespace
 
 int ladi_igemm_num_cfgs() { return NCFG; }
+// kernel symbol (as rocprofv3 prints it, without the "void " / argument list) a tile configuration launches; "" for an unknown id
+const char* ladi_igemm_cfg_symbol(int cfg) {
+    static std::string names[NCFG + 1];
+    if (cfg < 1 || cfg > NCFG) return "";
+    if (names[cfg].empty()) names[cfg] = cfg_symbol(cfg);
+    return names[cfg].c_str();
+}
 
 // the split-K admission rule (shared by the tuner and the workspace planner): few output tiles, deep K
 static bool splitk_admissible(const IGemmArgs& a, int c) {
     const long long tiles = (long long)((a.Q + kCfg[c].bq - 1) / kCfg[c].bq) * ((a.P + kCfg[c].bp - 1) / kCfg[c].bp);
     return !(tiles * kCfg[c].split > 1024 || tiles > 256 || (a.K / 64) / kCfg[c].split < 8);
+}
+
+// Everything that makes configuration c illegal (or, with `strict`, pointless) for this launch.  The tuner, a selection read from the
+// tune table and an explicitly requested configuration all pass through it: the tune key folds several epilogue features into one bit,
+// so a cached choice is re-validated against the launch it is applied to (a split-K selection must never reach a launch with a
+// per-pixel bias or an fp32 output, nor one whose planned slab was sized without it).
+static bool cfg_admissible(const IGemmArgs& a, int batch, int c, bool strict) {
+    const CfgInfo& ci = kCfg[c];
+    const bool geglu = a.act == LADI_ACT_GEGLU;
+    if (ci.base == 23) {
+        IGemmArgs t = a; t.stats = nullptr;
+        return ladi_linear_xs_eligible(t, batch, ci.tp, ci.bq);
+    }
+    if (a.ln_gamma && !a.ln_scratch) return false;                    // no scratch: only the fused (X-stationary) form
+    if (geglu && !ci.geglu_ok) return false;
+    if (ci.bk == 64 && ((a.C0 % 64) || (a.C1 % 64))) return false;
+    if (ci.split > 1 && (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel)) return false;
+    if (strict) {
+        if (ci.bq > 2 * a.Q && ci.bq > 64) return false;              // grossly oversized in Q
+        if (ci.split > 1 && !splitk_admissible(a, c)) return false;   // split-K: few tiles, deep K only
+    }
+    return true;
 }
 
 size_t ladi_igemm_splitk_ws_bytes(const IGemmArgs& a, int batch) {
@@ -457,20 +359,9 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                     float best_ms = 1e30f; int best_cfg = 0;
                     std::vector<std::pair<float, int>> cand;     // (ms per launch incl. penalty, cfg)
                                         for (int c = 1; c <= NCFG; ++c) {
-                        if (kCfg[c].blocks_per_cu < 2) continue;                       // 1-block/CU shapes never won
-                        if (a.ln_gamma && kCfg[c].base != 23 && !a.ln_scratch) continue;  // no scratch: only the fused form
-                        float penalty_ms = 0.f;
-                        if (kCfg[c].base == 23) {
-                            IGemmArgs t = a; t.stats = nullptr;
-                            if (!ladi_linear_xs_eligible(t, batch, kCfg[c].tp, kCfg[c].bq)) continue;
-                            // no fused statistics there: charge the separate statistics pass the consumer then needs (~3 TB/s read)
-                            if (a.stats) penalty_ms = 3.f * (float)((double)a.P * a.Q * 2.0 / 3.0e9);
-                        } else {
-                        if (geglu && !kCfg[c].geglu_ok) continue;
-                        if (((c >= 7 && c <= 15) || c == 22 || c >= 32) && ((a.C0 % 64) || (a.C1 % 64))) continue;
-                        if (kCfg[c].bq > 2 * a.Q && kCfg[c].bq > 64) continue;        // grossly oversized in Q
-                        if (kCfg[c].split > 1 && !splitk_admissible(a, c)) continue;    // split-K: few tiles, deep K only
-                        }
+                        if (!kCfg[c].tune || !cfg_admissible(a, batch, c, true)) continue;
+                        // X-stationary kernel: no fused statistics there, charge the separate statistics pass the consumer then needs (~3 TB/s read)
+                        const float penalty_ms = (kCfg[c].base == 23 && a.stats) ? 3.f * (float)((double)a.P * a.Q * 2.0 / 3.0e9) : 0.f;
                         if (ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes) != 0) continue;   // warm-up (also sets function attributes)
                         (void)hipEventRecord(e0, st);
                         for (int r = 0; r < 3; ++r) (void)ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes);
@@ -508,16 +399,13 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
             }
         }
     }
-    if (cfg >= 1 && cfg <= NCFG && kCfg[cfg].base == 23 && cfg_in == 0) {   // stale cache entry / shape drift: fall back to the model
-        IGemmArgs t = a; t.stats = nullptr;
-        if (!ladi_linear_xs_eligible(t, batch, kCfg[cfg].tp, kCfg[cfg].bq)) cfg = 0;
-    }
+    if (cfg >= 1 && cfg <= NCFG && cfg_in == 0 && !cfg_admissible(a, batch, cfg, true)) cfg = 0;   // stale table entry / key collision: cost model
     if (cfg == 0) {
         // fallback cost model: (waves of workgroups over the chip) x (tile work) / (per-tile efficiency)
         double best = 1e300;
         for (int c = 1; c <= NCFG; ++c) {
             const CfgInfo& ci = kCfg[c];
-            if ((geglu && !ci.geglu_ok) || ci.base == 23) continue;
+            if (ci.base == 23 || ci.split > 1 || !(ci.eff > 0.f) || !cfg_admissible(a, batch, c, false)) continue;
             const long long tiles = (long long)((a.Q + ci.bq - 1) / ci.bq) * ((a.P + ci.bp - 1) / ci.bp) * batch;
             const long long slots = 256LL * ci.blocks_per_cu;
             const double waves = (double)((tiles + slots - 1) / slots);
@@ -540,7 +428,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         if (!ladi_linear_xs_eligible(a, batch, kCfg[cfg].tp, kCfg[cfg].bq)) return -14;
     }
     if (geglu && !kCfg[cfg].geglu_ok) return -8;
-    if (((cfg >= 7 && cfg <= 15) || cfg == 22 || cfg >= 32) && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
+    if (kCfg[cfg].bk == 64 && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
     const int split = kCfg[cfg].split;
     if (split > 1) {
         if (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel) return -9;
@@ -572,29 +460,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     } else a.splitk = 1;
     const int batch_l = lbatch;
     int rc;
-    switch (kCfg[cfg].base) {
-        case 1: rc = launch_cfg<2, 2, 2, 4, 32, 3>(a, batch_l, st); break;
-        case 2: rc = launch_cfg<2, 2, 5, 2, 32, 2>(a, batch_l, st); break;
-        case 3: rc = launch_cfg<2, 2, 2, 2, 32, 3>(a, batch_l, st); break;
-        case 4: rc = launch_cfg<2, 2, 2, 1, 32, 3>(a, batch_l, st); break;
-        case 5: rc = launch_cfg<2, 2, 1, 1, 32, 3>(a, batch_l, st); break;
-        case 6: rc = launch_cfg<2, 2, 4, 2, 32, 3>(a, batch_l, st); break;
-        case 7: rc = launch_cfg<2, 2, 2, 2, 64, 2>(a, batch_l, st); break;
-        case 8: rc = launch_cfg<2, 2, 2, 4, 64, 2>(a, batch_l, st); break;
-        case 9: rc = launch_cfg<2, 2, 2, 1, 64, 3>(a, batch_l, st); break;
-        case 10: rc = launch_cfg<2, 2, 5, 2, 64, 2>(a, batch_l, st); break;
-        case 16: rc = launch_cfg<2, 2, 1, 1, 32, 4>(a, batch_l, st); break;
-        case 17: rc = launch_cfg<2, 2, 2, 1, 32, 4>(a, batch_l, st); break;
-        case 18: rc = launch_cfg<2, 2, 2, 2, 32, 4>(a, batch_l, st); break;
-        case 19: rc = launch_cfg<2, 4, 2, 2, 32, 3>(a, batch_l, st); break;
-        case 20: rc = launch_cfg<4, 2, 2, 2, 32, 3>(a, batch_l, st); break;
-        case 21: rc = launch_cfg<2, 4, 4, 2, 32, 3>(a, batch_l, st); break;
-        case 22: rc = launch_cfg<2, 4, 5, 2, 64, 2>(a, batch_l, st); break;
-        case 23: rc = ladi_launch_linear_xs(a, kCfg[cfg].tp, kCfg[cfg].bq, st); break;
-        case 32: rc = ladi_launch_igemm8(a, 5, 2, batch_l, st); break;
-        case 33: rc = ladi_launch_igemm8(a, 4, 2, batch_l, st); break;
-        default: rc = -7;
-    }
+    rc = launch_base(cfg, a, batch_l, st);
     if (prof) { (void)hipEventRecord(rec.e1, st); g_recs.push_back(rec); }   // the main kernel only (the reduce pass is its own symbol)
     if (rc == 0 && split > 1) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((full.P + 31) / 32), (unsigned)((full.Q + 63) / 64)), dim3(256), 0, st, ws, split, full);

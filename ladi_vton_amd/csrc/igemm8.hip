@@ -72,16 +72,20 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IGemmArgs a) {
     const int HoWo = a.Ho * a.Wo;
     const int HsWs = a.Hs * a.Ws;
     const int n_first = p0 / HoWo;
+    // activation descriptors: rebased to the tile's first sample and moved back by the largest negative window displacement, so that the
+    // per-lane offsets below are non-negative and constant over the K loop (see igemm_kernel.h: "Addressing of the LDS-DMA stream")
+    const int back_px = a.ups ? 0 : a.pad * a.Ws + a.pad;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<h16*>(a.src0 + (a.splitk > 1 ? 0 : (size_t)z * a.bs_src0) + (size_t)n_first * HsWs * a.ld0), 0, 0x7FFFFFFF, 0x00020000);
+        const_cast<h16*>(a.src0 + (a.splitk > 1 ? 0 : (size_t)z * a.bs_src0) + (size_t)n_first * HsWs * a.ld0) - (ptrdiff_t)back_px * a.ld0, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<h16*>(a.src1 ? a.src1 + (size_t)n_first * HsWs * a.ld1 : a.src0), 0, 0x7FFFFFFF, 0x00020000);
+        const_cast<h16*>(a.src1 ? a.src1 + (size_t)n_first * HsWs * a.ld1 - (ptrdiff_t)back_px * a.ld1 : a.src0), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<h16*>(a.W + (a.splitk > 1 ? 0 : (size_t)z * a.bs_w)), 0, 0x7FFFFFFF, 0x00020000);
 
     const int Hlog = a.ups ? 2 * a.Hs : a.Hs;
     const int Wlog = a.ups ? 2 * a.Ws : a.Ws;
-    int nb[NB], iy0[NB], ix0[NB];
+    int nb[NB], iy0[NB], ix0[NB];          // folded-upsample path only
+    unsigned vox0[NB], vox1[NB], vmask[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int p = p0 + r0 + 64 * i;
@@ -91,9 +95,21 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IGemmArgs a) {
         const int rem = pp - n * HoWo;
         const int oy = rem / a.Wo;
         const int ox = rem - oy * a.Wo;
-        iy0[i] = ok ? (oy * a.stride - a.pad) : -100000;
-        ix0[i] = ox * a.stride - a.pad;
+        const int y0 = oy * a.stride - a.pad, x0 = ox * a.stride - a.pad;
+        iy0[i] = ok ? y0 : -100000;
+        ix0[i] = x0;
         nb[i] = (n - n_first) * HsWs;
+        const int pix = nb[i] + y0 * a.Ws + x0 + back_px;
+        vox0[i] = (unsigned)((pix * a.ld0 + clog * 8) * 2);
+        vox1[i] = (unsigned)((pix * a.ld1 + clog * 8) * 2);
+        unsigned m = 0;
+        if (ok) {
+            int t = 0;
+            for (int dy = 0; dy < a.ksize; ++dy)
+                for (int dx = 0; dx < a.ksize; ++dx, ++t)
+                    if ((unsigned)(y0 + dy) < (unsigned)Hlog && (unsigned)(x0 + dx) < (unsigned)Wlog) m |= 1u << t;
+        }
+        vmask[i] = m;
     }
     const int Ct = a.C0 + a.C1;
     const int ldw = a.ldw ? a.ldw : a.K;
@@ -115,6 +131,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IGemmArgs a) {
     }
     int tdy = tap / a.ksize, tdx = tap - (tap / a.ksize) * a.ksize;
     bool st_valid = nk > 0;            // the K tile being staged exists (tail pieces are issued out of range: zeros, same vmcnt cadence)
+    unsigned stbit = st_valid ? (1u << tap) : 0u;   // validity-mask bit of the staged tap (0: every pixel lane out of range)
 
     // one piece of the K tile described by (tap, cb, tdy, tdx) into buffer `buf`
     auto issue_piece = [&](auto IC, char* buf) {
@@ -123,23 +140,30 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IGemmArgs a) {
             const bool s0 = cb < a.C0;
             const __amdgpu_buffer_rsrc_t rs = s0 ? rs0 : rs1;
             const int ld = s0 ? a.ld0 : a.ld1;
-            const int c = (s0 ? cb : cb - a.C0) + clog * 8;
-            int iy = iy0[i] + tdy, ix = ix0[i] + tdx;
-            const bool ok = st_valid && ((unsigned)iy < (unsigned)Hlog) && ((unsigned)ix < (unsigned)Wlog);
-            if (a.ups) { iy >>= 1; ix >>= 1; }
-            const unsigned vo = ok ? (unsigned)(((nb[i] + iy * a.Ws + ix) * ld + c) * 2) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(buf + BQ * BK * 2 + i * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+            const int csub = s0 ? cb : cb - a.C0;
+            if (!a.ups) {      // per-lane offset fixed, the tap / channel-chunk displacement is the wave-uniform soffset
+                const unsigned so = (unsigned)(((tdy * a.Ws + tdx) * ld + csub) * 2);
+                const unsigned vo = (vmask[i] & stbit) ? (s0 ? vox0[i] : vox1[i]) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(buf + BQ * BK * 2 + i * 8192 + wave * 1024), 16, vo, so, 0, 0);
+            } else {
+                int iy = iy0[i] + tdy, ix = ix0[i] + tdx;
+                const bool ok = st_valid && ((unsigned)iy < (unsigned)Hlog) && ((unsigned)ix < (unsigned)Wlog);
+                iy >>= 1; ix >>= 1;
+                const unsigned vo = ok ? (unsigned)(((nb[i] + iy * a.Ws + ix) * ld + csub + clog * 8) * 2) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(buf + BQ * BK * 2 + i * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+            }
         } else {
             constexpr int q = i - NB;
-            const int k0 = tap * Ct + cb;
-            const unsigned vo = (wbase[q] == OOB || !st_valid) ? OOB : wbase[q] + (unsigned)(k0 * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(buf + q * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+            const unsigned so = (unsigned)((tap * Ct + cb) * 2);
+            const unsigned vo = st_valid ? wbase[q] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(buf + q * 8192 + wave * 1024), 16, vo, so, 0, 0);
         }
     };
     auto advance_stage = [&](int kt_staged_next) {
         if (++tdx == a.ksize) { tdx = 0; ++tdy; }
         if (++tap == ntap) { tap = 0; tdy = 0; tdx = 0; cb += BK; }
         st_valid = kt_staged_next < nk;
+        stbit = st_valid ? (1u << tap) : 0u;
     };
 
     f32x16 acc[TQ][TP];
@@ -266,6 +290,7 @@ int launch_cfg8(IGemmArgs a, int batch, hipStream_t st) {
 }  // namespace
 
 int ladi_launch_igemm8(const IGemmArgs& a, int tq, int tp, int batch, hipStream_t st) {
+#ifdef LADI_ABLATION      // timing-only instantiations (WRONG results): compiled into tools/ builds only, never into the shipped library
     static const int abl = getenv("LADI_IGEMM8_ABL") ? atoi(getenv("LADI_IGEMM8_ABL")) : 0;
     if (abl && tq == 5 && tp == 2) {
         switch (abl) {
@@ -276,7 +301,13 @@ int ladi_launch_igemm8(const IGemmArgs& a, int tq, int tp, int batch, hipStream_
             default: break;
         }
     }
+#endif
     if (tq == 5 && tp == 2) return launch_cfg8<5, 2>(a, batch, st);
     if (tq == 4 && tp == 2) return launch_cfg8<4, 2>(a, batch, st);
+    if (tq == 2 && tp == 2) return launch_cfg8<2, 2>(a, batch, st);
+    if (tq == 4 && tp == 1) return launch_cfg8<4, 1>(a, batch, st);
+    if (tq == 2 && tp == 1) return launch_cfg8<2, 1>(a, batch, st);
+    if (tq == 5 && tp == 1) return launch_cfg8<5, 1>(a, batch, st);
+    if (tq == 3 && tp == 2) return launch_cfg8<3, 2>(a, batch, st);
     return -7;
 }

@@ -1,0 +1,283 @@
+// igemm_kernel: the ring-staged implicit-GEMM kernel template (see igemm.hip for the family overview) and its launcher template.
+// Included by the instantiation units igemm_inst_*.hip only: every tile shape is compiled in its own translation unit so that the
+// build parallelises (one instantiation inlines the whole fused epilogue and takes ~15 s of hipcc).
+//
+// Orientation: D[q][p] = sum_k W[q][k] * X[p][k]   (q = output channel, p = output pixel / token)
+//   A operand (MFMA rows)  = weight tile  [BQ][BK]  in LDS
+//   B operand (MFMA cols)  = gathered activation tile [BP][BK] in LDS (im2col is done by the per-lane gather address)
+//
+// Addressing of the LDS-DMA stream (round 3).  A DMA instruction takes a per-lane byte offset (VGPR) and a wave-uniform byte offset
+// (SGPR, `soffset`).  Everything that changes from K step to K step is uniform: the tap's window displacement (dy*Ws + dx)*ld, the
+// channel chunk, the weight column k0.  So the per-lane offsets are computed ONCE before the loop --
+//     weights : q*ldw + chunk                                   (or OOB for rows >= Q)
+//     pixels  : ((n, oy*stride - pad, ox*stride - pad) -> pixel index)*ld + chunk, rebased so that the top-left halo tap is offset 0
+//     halo    : one validity bit per (row, tap), 16 taps at most
+// -- and a K step costs one v_and / v_cmp / v_cndmask per pixel row plus scalar arithmetic, instead of ~13 VALU instructions and two
+// exec-mask branches per row (the address stream was about as long as the MFMA stream of the 128x128 tile).  The folded nearest-2x
+// upsample keeps per-lane addressing (its source pixel depends on the parity of the lane's output pixel).
+#pragma once
+#include "common.h"
+#include "kernels.h"
+#include "igemm_common.h"
+
+namespace {
+
+// WQ x WP waves, wave tile (TQ*32 channels) x (TP*32 pixels), K step BK, NST-stage LDS ring, OCC = minimum waves per SIMD the register
+// allocation must allow (2: two workgroups of 4 waves per CU; 1: one wave per SIMD with the whole 512-entry register file),
+// ILV = 1: the DMA instructions of the next stage are issued in NKK slices between the MFMA groups of the current K step (one wave per
+// SIMD has no partner wave to cover an un-interleaved issue block)
+template <int WQ, int WP, int TQ, int TP, int BK, int NST, int OCC, int ILV>
+__global__ __launch_bounds__(64 * WQ * WP, OCC) void igemm_kernel(const IGemmArgs a) {
+    // The body is compiled in the device pass only.  hipcc's HOST pass instantiates kernel bodies too (to defer their diagnostics) and, for
+    // this body, silently drops the instantiation together with the kernel's host stub (undefined symbol at load time, no diagnostic at any
+    // -W level; bisected to the DMA-issue lambdas, cause unknown).  The stub needs the signature only.
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
+    constexpr int CPR = BK / 8;          // 16-byte chunks per LDS row
+    constexpr int NT = 64 * WQ * WP;      // threads per workgroup (4 or 8 waves)
+    constexpr int RPP = NT / CPR;        // tile rows covered by one pass of the workgroup
+    constexpr int RQ = BQ / RPP, RP = BP / RPP;
+    constexpr int STAGE = (BQ + BP) * BK;  // halves per stage
+    constexpr int NKK = BK / 16;
+    static_assert(NST >= 2 && NST <= 5, "ring depth");
+    static_assert(BQ % RPP == 0 && BP % RPP == 0, "tile rows must be a multiple of the rows per pass");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    h16* smem = reinterpret_cast<h16*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
+    int qt, pt;
+    {
+        const int b = blockIdx.x;
+        if (a.tile_map == 1) {          // pixel tiles split across the 8 XCDs, q fastest inside an XCD
+            const int npx = (np + 7) >> 3, xcd = b & 7, loc = b >> 3;
+            pt = xcd * npx + loc / nq; qt = loc % nq;
+            if (pt >= np) return;
+        } else if (a.tile_map == 2) {   // channel tiles split across the XCDs, p fastest inside an XCD
+            const int nqx = (nq + 7) >> 3, xcd = b & 7, loc = b >> 3;
+            qt = xcd * nqx + loc / np; pt = loc % np;
+            if (qt >= nq) return;
+        } else { qt = b % nq; pt = b / nq; }
+    }
+    const int q0 = qt * BQ, p0 = pt * BP;
+    const int z = blockIdx.z;
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int cphys = tid % CPR;          // physical chunk this lane's DMA lands in
+    const int r0 = tid / CPR;             // row within a pass
+    const int clog = (BK == 64) ? (cphys ^ ((r0 >> 1) & 7)) : (cphys ^ ((r0 >> 2) & 3));  // logical chunk it must fetch
+
+    const int HoWo = a.Ho * a.Wo;
+    const int HsWs = a.Hs * a.Ws;
+    const int n_first = p0 / HoWo;
+    const int Hlog = a.ups ? 2 * a.Hs : a.Hs;
+    const int Wlog = a.ups ? 2 * a.Ws : a.Ws;
+    const int ntap = a.ksize * a.ksize;
+    const int Ct = a.C0 + a.C1;
+    const int ldw = a.ldw ? a.ldw : a.K;
+    constexpr unsigned OOB = 0x80000000u;
+
+    // ---- buffer descriptors (wave-uniform).  Activation descriptors are rebased to the tile's first sample so that 32-bit byte offsets
+    //      never overflow, and moved BACK by the largest negative window displacement (pad rows + pad pixels) so that every in-range tap
+    //      has a non-negative offset (out-of-image taps are never dereferenced: their lanes carry the OOB offset).
+    const int back_px = a.ups ? 0 : a.pad * a.Ws + a.pad;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.src0 + (a.splitk > 1 ? 0 : (size_t)z * a.bs_src0) + (size_t)n_first * HsWs * a.ld0) - (ptrdiff_t)back_px * a.ld0, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.src1 ? a.src1 + (size_t)n_first * HsWs * a.ld1 - (ptrdiff_t)back_px * a.ld1 : a.src0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.W + (a.splitk > 1 ? 0 : (size_t)z * a.bs_w)), 0, 0x7FFFFFFF, 0x00020000);
+
+    // ---- per-thread row decode (constant over the K loop)
+    int nb[RP], iy0[RP], ix0[RP];        // folded-upsample path only
+    unsigned vox0[RP], vox1[RP], vmask[RP];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        const int p = p0 + r0 + RPP * i;
+        const bool ok = p < a.P;
+        const int pp = ok ? p : 0;
+        const int n = pp / HoWo;
+        const int rem = pp - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        const int y0 = oy * a.stride - a.pad, x0 = ox * a.stride - a.pad;
+        iy0[i] = ok ? y0 : -100000;       // invalid rows fail the bounds test
+        ix0[i] = x0;
+        nb[i] = (n - n_first) * HsWs;
+        const int pix = nb[i] + y0 * a.Ws + x0 + back_px;          // >= 0: index of the top-left tap relative to the rebased descriptor
+        vox0[i] = (unsigned)((pix * a.ld0 + clog * 8) * 2);
+        vox1[i] = (unsigned)((pix * a.ld1 + clog * 8) * 2);
+        unsigned m = 0;
+        if (ok) {
+            int t = 0;
+            for (int dy = 0; dy < a.ksize; ++dy)
+                for (int dx = 0; dx < a.ksize; ++dx, ++t)
+                    if ((unsigned)(y0 + dy) < (unsigned)Hlog && (unsigned)(x0 + dx) < (unsigned)Wlog) m |= 1u << t;
+        }
+        vmask[i] = m;
+    }
+    unsigned wbase[RQ];
+#pragma unroll
+    for (int i = 0; i < RQ; ++i) {
+        const int q = q0 + r0 + RPP * i;
+        wbase[i] = (q < a.Q) ? (unsigned)(((size_t)q * ldw + clog * 8) * 2) : OOB;
+    }
+
+    // split-K: grid.z slices the K loop (a.splitk > 1); each slice writes an fp32 partial tile (see splitk_reduce_kernel)
+    // K-loop order: channel chunk OUTER, tap INNER.  The 9 taps of one channel chunk read overlapping input rows in consecutive
+    // steps, so all but the first hit in L2.  Weights stay tap-major in memory: only the sequence of k offsets changes.
+    int nk = a.K / BK;
+    int tap = 0, cb = 0;  // (tap, channel base) of the NEXT stage to issue
+    if (a.splitk > 1) {
+        const int sps = (nk + a.splitk - 1) / a.splitk;
+        const int start = z * sps;
+        nk = max(0, min(sps, nk - start));
+        cb = (start / ntap) * BK; tap = start - (start / ntap) * ntap;
+    }
+    int tdy = tap / a.ksize, tdx = tap - (tap / a.ksize) * a.ksize;   // window offset of `tap`, advanced incrementally (no per-step division)
+
+    // DMA instructions [i0, i1) of the stage described by (tap, cb, tdy, tdx) into ring slot `stage`: indices < RQ are weight rows, the
+    // rest pixel rows.  i0 / i1 are compile-time constants at every call site (the loops unroll and the range tests fold).
+    // (a plain lambda on purpose: a generic lambda nested in the k-group lambda below is silently dropped by the HOST pass of hipcc --
+    // deferred diagnostics -- and takes the kernel's host stub with it)
+    auto issue_part = [&](int stage, int i0, int i1) {
+        const bool s0 = cb < a.C0;
+        const __amdgpu_buffer_rsrc_t rs = s0 ? rs0 : rs1;
+        const int ld = s0 ? a.ld0 : a.ld1;
+        const int csub = s0 ? cb : cb - a.C0;
+        char* sbase = smem_raw + (size_t)stage * (STAGE * 2) + wave * 1024;
+        const unsigned so_w = (unsigned)((tap * Ct + cb) * 2);
+#pragma unroll
+        for (int i = 0; i < RQ; ++i)
+            if (i >= i0 && i < i1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(sbase + i * (RPP * BK * 2)), 16, wbase[i], so_w, 0, 0);
+        if (!a.ups) {
+            const unsigned so_x = (unsigned)(((tdy * a.Ws + tdx) * ld + csub) * 2);
+            const unsigned bit = 1u << tap;
+#pragma unroll
+            for (int j = 0; j < RP; ++j)
+                if (RQ + j >= i0 && RQ + j < i1) {
+                    const unsigned vo = (vmask[j] & bit) ? (s0 ? vox0[j] : vox1[j]) : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sbase + (BQ * BK * 2) + j * (RPP * BK * 2)), 16, vo, so_x, 0, 0);
+                }
+        } else {
+            const int c = csub + clog * 8;
+#pragma unroll
+            for (int j = 0; j < RP; ++j)
+                if (RQ + j >= i0 && RQ + j < i1) {
+                    int iy = iy0[j] + tdy, ix = ix0[j] + tdx;
+                    const bool ok = ((unsigned)iy < (unsigned)Hlog) && ((unsigned)ix < (unsigned)Wlog);
+                    iy >>= 1; ix >>= 1;
+                    const unsigned vo = ok ? (unsigned)(((nb[j] + iy * a.Ws + ix) * ld + c) * 2) : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sbase + (BQ * BK * 2) + j * (RPP * BK * 2)), 16, vo, 0, 0, 0);
+                }
+        }
+    };
+    auto advance = [&]() {
+        if (++tdx == a.ksize) { tdx = 0; ++tdy; }
+        if (++tap == ntap) { tap = 0; tdy = 0; tdx = 0; cb += BK; }
+    };
+    constexpr int L = RQ + RP;  // DMA instructions per stage per wave
+    auto issue = [&](int stage) { issue_part(stage, 0, L); advance(); };
+
+    const int wq = wave / WP, wp = wave % WP;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    f32x16 acc[TQ][TP];
+#pragma unroll
+    for (int i = 0; i < TQ; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: NST-1 stages in flight
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) issue(s);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // my part of stage kt has landed (later stages may stay in flight), then rendezvous: every wave's part of stage kt is
+        // visible and every wave has finished reading the ring slot that is refilled next
+        {
+            const int later = min(NST - 2, nk - 1 - kt);   // stages issued after stage kt that may stay in flight
+            if (NST >= 5 && later >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * L) : "memory");
+            else if (NST >= 4 && later >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * L) : "memory");
+            else if (NST >= 3 && later >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(L) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        const bool more = kt + NST - 1 < nk;
+        const int slot = (kt + NST - 1) % NST;
+        if constexpr (!ILV) { if (more) issue(slot); }
+        const h16* sW = smem + (kt % NST) * STAGE;
+        const h16* sX = sW + BQ * BK;
+        // fragments are double-buffered in registers: the ds_reads of k-group kk+1 (and, interleaved mode, a slice of the next stage's
+        // DMA instructions) are issued AHEAD of the MFMAs of k-group kk, so the LDS latency runs under the matrix pipe even with one wave
+        // per SIMD (the DMA instructions pin the order: the compiler cannot move an LDS read across them on its own)
+        h16x8 af[2][TQ], bf[2][TP];
+        auto load_frags = [&](auto Kc) {
+            constexpr int kk = decltype(Kc)::value;
+            const int chunk = kk * 2 + hh;
+#pragma unroll
+            for (int i = 0; i < TQ; ++i) af[kk & 1][i] = *reinterpret_cast<const h16x8*>(sW + swz<BK>((wq * TQ + i) * 32 + l31, chunk));
+#pragma unroll
+            for (int j = 0; j < TP; ++j) bf[kk & 1][j] = *reinterpret_cast<const h16x8*>(sX + swz<BK>((wp * TP + j) * 32 + l31, chunk));
+        };
+        load_frags(IntC<0>{});
+        static_for<0, NKK>([&](auto Kc) {
+            constexpr int kk = decltype(Kc)::value;
+            if constexpr (kk + 1 < NKK) load_frags(IntC<kk + 1>{});
+            if constexpr (ILV) {
+                // a 2-stage ring waits for the stage it issues in the SAME K step: front-load its DMA instructions into the first NKK-1
+                // k-groups so that the last of them has at least one group of MFMAs (~500 cycles) to land before the barrier
+                constexpr int G = (NST == 2 && NKK > 1) ? NKK - 1 : NKK;
+                if constexpr (kk < G) {
+                    constexpr int I0 = (L * kk) / G, I1 = (L * (kk + 1)) / G;
+                    if (more) issue_part(slot, I0, I1);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TQ; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+        });
+        if constexpr (ILV) { if (more) advance(); }
+    }
+
+    igemm_epilogue<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane);
+#endif
+}
+
+template <int WQ, int WP, int TQ, int TP, int BK, int NST, int OCC, int ILV>
+int launch_cfg(IGemmArgs a, int batch, hipStream_t st) {
+    constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
+    constexpr int RING = NST * (BQ + BP) * BK * (int)sizeof(h16), EPI = igemm_epilogue_lds_bytes<WQ, WP, TQ>();
+    constexpr int SMEM = RING > EPI ? RING : EPI;
+    static_assert(SMEM <= 160 * 1024, "LDS budget of one CU");
+    static bool attr_set = false;
+    auto kfn = igemm_kernel<WQ, WP, TQ, TP, BK, NST, OCC, ILV>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+            return -10;
+        attr_set = true;
+    }
+    const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
+    int blocks = nq * np;
+    a.tile_map = 0;
+    if (batch == 1 || a.splitk > 1) {
+        if (np >= 16) { a.tile_map = 1; blocks = 8 * ((np + 7) / 8) * nq; }
+        else if (nq >= 16) { a.tile_map = 2; blocks = 8 * ((nq + 7) / 8) * np; }
+    }
+    dim3 grid((unsigned)blocks, 1, (unsigned)batch);
+    hipLaunchKernelGGL(kfn, grid, dim3(64 * WQ * WP), SMEM, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+}  // namespace
+
+// one line per tile shape in an instantiation unit: the external entry point igemm.hip dispatches to (kernel and launcher template stay
+// internal to the unit, like every other kernel of the library)
+#define LADI_IGEMM_INSTANTIATE(BASE, WQ, WP, TQ, TP, BK, NST, OCC, ILV) \
+    int ladi_igemm_launch_base_##BASE(IGemmArgs a, int batch, hipStream_t st) { return launch_cfg<WQ, WP, TQ, TP, BK, NST, OCC, ILV>(a, batch, st); }

@@ -147,4 +147,6 @@ int ladi_launch_lat_pix_to_nchw(const float* src, int B, int hw, float* dst, hip
 void ladi_igemm_profile_enable(int on);
 void ladi_igemm_autotune(int on);   // measured tile-shape selection on first use of a problem shape (default on)
 int ladi_igemm_tuned_count();
+int ladi_igemm_num_cfgs();
+const char* ladi_igemm_cfg_symbol(int cfg);
 int ladi_igemm_profile_collect(double* out, int n_out);
