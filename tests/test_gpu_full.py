@@ -68,6 +68,7 @@ def test_full_adapter_vs_oracle():
     ref = M.adapter_forward(sd, cfg, x)
     got = ad(x.to(U.dev())).float().cpu()
     assert got.shape == (3, 16384)
+    U.record_parity("inversion_adapter_full", dict(psnr_db=round(U.psnr(got, ref), 2), rel_l2=U.rel_l2(got, ref)))
     assert U.psnr(got, ref) >= 50.0, U.psnr(got, ref)
 
 
@@ -92,8 +93,10 @@ def test_full_text_encoder_vs_oracle():
     out = L.encode_text_word_embedding(enc, ids, we.to(U.dev()), NV)
     torch.cuda.synchronize()
     got, pooled = out.last_hidden_state.float().cpu(), out.pooler_output.float().cpu()
-    assert U.psnr(got, ref) >= 45.0 and U.rel_l2(got, ref) <= 1e-2, (U.psnr(got, ref), U.rel_l2(got, ref))
-    assert U.rel_l2(pooled, ref_pooled) <= 1e-2
+    m = dict(hidden_psnr_db=round(U.psnr(got, ref), 2), hidden_rel_l2=U.rel_l2(got, ref), pooled_rel_l2=U.rel_l2(pooled, ref_pooled))
+    U.record_parity("text_encoder_full_23_layers", m)
+    # measured on MI355X: rel-L2 1.3e-3 on the hidden states (23 layers of fp16 storage); asserted at ~2x the measured value
+    assert m["hidden_psnr_db"] >= 55.0 and m["hidden_rel_l2"] <= 3e-3 and m["pooled_rel_l2"] <= 1e-2, m
 
 
 def test_full_vision_encoder_feeds_adapter_vs_oracle():
@@ -109,11 +112,15 @@ def test_full_vision_encoder_feeds_adapter_vs_oracle():
     torch.cuda.synchronize()
     got = out.last_hidden_state.float().cpu()
     assert got.shape == (2, 257, 1280)
-    assert U.psnr(got, ref) >= 40.0 and U.rel_l2(got, ref) <= 2e-2, (U.psnr(got, ref), U.rel_l2(got, ref))
-    assert U.rel_l2(out.pooler_output.float().cpu(), ref_pooled) <= 2e-2
+    m = dict(hidden_psnr_db=round(U.psnr(got, ref), 2), hidden_rel_l2=U.rel_l2(got, ref),
+             pooled_rel_l2=U.rel_l2(out.pooler_output.float().cpu(), ref_pooled))
+    # measured on MI355X: rel-L2 1.4e-3 on the hidden states (32 layers); asserted at ~2x the measured value
+    assert m["hidden_psnr_db"] >= 50.0 and m["hidden_rel_l2"] <= 3e-3 and m["pooled_rel_l2"] <= 1e-2, m
     acfg = C.ADAPTER_FULL
     asd = C.synth_state_dict(C.adapter_shapes(acfg), "adapter.")
     ad = L.NativeInversionAdapter(acfg, asd)
     we = ad(out.last_hidden_state).float().cpu()
     we_ref = M.adapter_forward(asd, acfg, ref)
-    assert U.psnr(we, we_ref) >= 40.0, U.psnr(we, we_ref)
+    m["adapter_after_vision_psnr_db"] = round(U.psnr(we, we_ref), 2)
+    U.record_parity("vision_encoder_full_32_layers_to_adapter", m)
+    assert m["adapter_after_vision_psnr_db"] >= 40.0, m

@@ -21,9 +21,13 @@ def _rand(shape, seed, scale=1.0):
 
 
 # --------------------------------------------------------------------------------------------------------------- igemm
-@pytest.mark.parametrize("cfg", [19, 20, 21, 22, 32, 33])
+NEW_RING = [39, 40, 41, 42, 43, 44, 45, 47, 48]      # round 3: one-wave-per-SIMD tiles / deep rings / interleaved DMA issue (igemm_tiles.h)
+NEW_IGEMM8 = [54, 55, 56, 57, 58]                      # round 3: more shapes of the phase-staggered 8-wave pipeline
+
+
+@pytest.mark.parametrize("cfg", [19, 20, 21, 22, 32, 33] + NEW_RING + NEW_IGEMM8)
 def test_conv3x3_eight_wave_tiles(cfg):
-    """8-wave (512-thread) workgroup tile shapes, ragged pixel count, residual + statistics-free epilogue"""
+    """large workgroup tile shapes (8 waves, or 4 waves with one wave per SIMD), ragged pixel count, residual + statistics-free epilogue"""
     N, cin, cout, h, w = 3, 128, 320, 20, 13
     x, wt, b = _rand((N, cin, h, w), 70), _rand((cout, cin, 3, 3), 71, 1 / math.sqrt(9 * cin)), _rand((cout,), 72, 0.1)
     res = _rand((N, cout, h, w), 73)
@@ -96,7 +100,7 @@ def test_linear_x_stationary_rejects_unsupported():
         U.igemm(U.nhwc16(x), U.pack_conv_weight(w), 320, ksize=1, act="silu", cfg=25)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 16, 17, 18, 19, 20, 21, 22, 32, 33])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 16, 17, 18, 19, 20, 21, 22, 32, 33] + NEW_RING + NEW_IGEMM8)
 def test_mfma_layout_asymmetric(cfg):
     """transpose-detecting check of the MFMA fragment / accumulator mapping: 1x1 'conv' with an asymmetric weight."""
     N, H, W, C, Q = 1, 16, 24, 64, 192
@@ -121,7 +125,7 @@ def test_conv3x3_bias_res_temb(cin, cout, h, w, cfg):
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 34, 35, 36, 37, 38])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 34, 35, 36, 37, 38, 46, 49, 50, 51, 52, 53, 59, 60, 61])
 def test_conv3x3_split_k(cfg):
     """split-K variants (fp32 partial slices + reduce pass that applies the epilogue) on a few-tile / deep-K problem"""
     N, cin, cout, h, w = 2, 512, 192, 8, 6
@@ -132,9 +136,10 @@ def test_conv3x3_split_k(cfg):
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [32, 33])
+@pytest.mark.parametrize("cfg", [32, 33] + NEW_IGEMM8 + [3, 7, 9, 39, 40, 42, 45, 47])
 def test_igemm8_staggered_pipeline_shapes(cfg):
-    """the phase-staggered large-tile kernel (igemm8.hip) on every gather variant and K-loop length it has to pipeline: a single K tile
+    """the phase-staggered large-tile kernel (igemm8.hip) -- and the ring kernel with its hoisted DMA addressing (uniform soffset per tap,
+    halo validity masks) -- on every gather variant and K-loop length it has to pipeline: a single K tile
     (prologue only), odd / even K-tile counts, two-source concat, stride 2, folded 2x upsample, ragged pixel and channel tiles"""
     # 1x1, K = 64: one K tile; K = 192: three
     for cin, cout, hw in ((64, 96, (9, 7)), (192, 320, (24, 16)), (128, 700, (40, 13))):
@@ -157,7 +162,7 @@ def test_igemm8_staggered_pipeline_shapes(cfg):
     assert U.rel_l2(U.to_nchw(y), F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, padding=1)) < TOL
 
 
-@pytest.mark.parametrize("cfg", [32, 33, 35])
+@pytest.mark.parametrize("cfg", [32, 33, 35, 54, 56, 57, 39, 40, 42, 44, 47])
 def test_igemm8_is_race_free_and_deterministic(cfg):
     """race screen for the counted-vmcnt / staggered-barrier pipeline: a UNet-sized conv (many workgroups, 45 K tiles) repeated 25 times
     must give bitwise identical outputs, and match the plain-tile kernel to fp16 rounding"""
@@ -170,6 +175,34 @@ def test_igemm8_is_race_free_and_deterministic(cfg):
     base = U.igemm(X, Wp, cout, bias=b, cfg=7)
     assert U.rel_l2(first.float().cpu(), base.float().cpu()) < 1e-3
     assert U.rel_l2(U.to_nchw(first), F.conv2d(x, wt, b, padding=1)) < TOL
+
+
+@pytest.mark.parametrize("cfg", [7, 9, 32, 39, 40, 45, 54, 56])
+def test_fused_output_statistics(cfg):
+    """per-channel partial statistics of the output (sum, sum of squares of the fp16-rounded values) written by the epilogue for the
+    consuming GroupNorm: rows of [Q][2] per (TP*32)-pixel block -- 96-pixel blocks for the 320x192 / 256x192 tiles.  Summed over all rows
+    they must equal the per-channel totals of the stored output."""
+    lib = _lib.load()
+    N, cin, cout, h, w_ = 2, 128, 320, 24, 16                   # 384 pixels per sample: a multiple of 64, 96 and 128
+    x, wt, b = _rand((N, cin, h, w_), 95), _rand((cout, cin, 3, 3), 96, 1 / math.sqrt(9 * cin)), _rand((cout,), 97, 0.1)
+    X, Wp, B16 = U.nhwc16(x), U.pack_conv_weight(wt), b.half().to(U.dev())
+    out = torch.zeros((N, h, w_, cout), dtype=torch.float16, device=U.dev())
+    rows = N * h * w_ // 32
+    stats = torch.zeros((rows, cout, 2), dtype=torch.float32, device=U.dev())
+    d = _lib.IGemmDesc()
+    d.src0, d.C0, d.ld0 = X.data_ptr(), cin, cin
+    d.Hs, d.Ws, d.Ho, d.Wo, d.P = h, w_, h, w_, N * h * w_
+    d.ksize, d.stride, d.pad, d.ups = 3, 1, 1, 0
+    d.W, d.Q, d.K, d.ldw = Wp.data_ptr(), cout, 9 * cin, 0
+    d.bias, d.act, d.out_scale = B16.data_ptr(), U.ACT["silu"], 1.0
+    d.out, d.ldo, d.stats = out.data_ptr(), cout, stats.data_ptr()
+    assert lib.ladi_op_igemm(ctypes.byref(d), 1, cfg, stream_ptr()) == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    ref = F.silu(F.conv2d(x, wt, b, padding=1))
+    assert U.rel_l2(U.to_nchw(out), ref) < TOL
+    o = out.float().reshape(-1, cout)
+    tot = stats.sum(0).cpu()
+    assert U.rel_l2(tot[:, 0], o.sum(0).cpu()) < 1e-4 and U.rel_l2(tot[:, 1], (o * o).sum(0).cpu()) < 1e-4
 
 
 def test_conv3x3_stride2_pad1_and_asym():

@@ -110,3 +110,20 @@ def cpu_quota_threads():
     except Exception:
         pass
     return n
+
+
+def record_parity(key, value, name="parity_r03.json"):
+    """append a measured parity value to gpurun_out/<name> (copied to profiles/r03_parity.json after the run): every tolerance asserted in
+    the GPU tests has its measured value on record"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", root), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, name)
+        blob = json.load(open(path)) if os.path.exists(path) else {}
+        blob[key] = value
+        json.dump(blob, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
