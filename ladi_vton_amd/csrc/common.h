@@ -101,7 +101,7 @@ struct IGemmArgs {
     void* out; int ldo;  // [P][ldo]
     int out_f32;         // 1: store fp32
     float* stats;        // optional per-channel partial statistics of the OUTPUT: rows of [Q][2] (sum, sumsq), see kernels.h
-    int krot;            // set by the launcher: 1 = rotate the start of the K loop per workgroup (igemm_kernel.h)
+    int stats_groups;    // unused
     int splitk;          // set by the launcher: > 1 = grid.z slices K, fp32 partials to `out` (+ z*bs_out), reduced by a 2nd kernel
     int tile_map;        // set by the launcher: 0 plain, 1 pixel tiles split over XCDs, 2 channel tiles split over XCDs
     // optional LayerNorm of the pixel operand: x <- (x - mean) * rstd * gamma + beta over the C0 channels of every pixel, rounded to

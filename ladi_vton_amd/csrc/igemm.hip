@@ -111,7 +111,7 @@ struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; in
 // tile configurations (0 = choose: measured per shape when autotuning is on, else the cost model below).
 // {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K,
 //  K step, offered to the tuner}
-constexpr int NCFG = 61;
+constexpr int NCFG = 73;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1, 0, false},
     {128, 256, 2, true, 0.80f, 4, 1, 1, 32, true},   // 1: <2,2,2,4> BK32 NST3
@@ -182,7 +182,22 @@ const CfgInfo kCfg[NCFG + 1] = {
     {128, 256, 1, false, 0.00f, 2, 54, 2, 64, true},  // 59: cfg 54 + split-K 2
     {256, 128, 1, false, 0.00f, 1, 55, 2, 64, true},  // 60: cfg 55 + split-K 2
     {320, 128, 1, false, 0.00f, 1, 57, 2, 64, true},  // 61: cfg 57 + split-K 2
+    // 62..73 (round 3): loader / consumer kernel (igemm_lc.hip): 2 x 2 consumer waves that only read LDS and issue MFMAs + 2 loader waves
+    // that keep NST-1 whole K tiles of LDS-DMA in flight; one workgroup (6 waves) per CU
+    {128, 128, 1, true, 0.00f, 2, 62, 1, 64, true},   // 62: 128x128, 4-deep ring (128 KB)
+    {128, 128, 1, true, 0.00f, 2, 63, 1, 64, true},   // 63: 128x128, 5-deep ring (160 KB)
+    {256, 128, 1, true, 0.00f, 2, 64, 1, 64, true},   // 64: 256x128, 3-deep ring (144 KB)
+    {128, 256, 1, true, 0.00f, 4, 65, 1, 64, true},   // 65: 128x256, 3-deep ring (144 KB)
+    {128, 64, 1, true, 0.00f, 1, 66, 1, 64, true},    // 66: 128x64, 6-deep ring (144 KB)
+    {320, 128, 1, false, 0.00f, 2, 67, 1, 64, true},  // 67: 320x128, 2-deep ring (112 KB)
+    {192, 192, 1, false, 0.00f, 3, 68, 1, 64, true},  // 68: 192x192, 3-deep ring (144 KB)
+    {128, 128, 1, false, 0.00f, 2, 62, 2, 64, true},  // 69: cfg 62 + split-K 2
+    {256, 128, 1, false, 0.00f, 2, 64, 2, 64, true},  // 70: cfg 64 + split-K 2
+    {256, 128, 1, false, 0.00f, 2, 64, 4, 64, true},  // 71: cfg 64 + split-K 4
+    {128, 64, 1, false, 0.00f, 1, 66, 4, 64, true},   // 72: cfg 66 + split-K 4
+    {128, 128, 1, false, 0.00f, 2, 62, 4, 64, true},  // 73: cfg 62 + split-K 4
 };
+inline bool is_lc(int base) { return base >= 62 && base <= 68; }
 
 // rocprofv3's name of the kernel a configuration launches (bench.py groups its per-launch timings by symbol)
 std::string cfg_symbol(int c) {
@@ -196,6 +211,13 @@ std::string cfg_symbol(int c) {
         case 56: return "igemm8_kernel<2, 1, 0>";
         case 57: return "igemm8_kernel<5, 1, 0>";
         case 58: return "igemm8_kernel<3, 2, 0>";
+        case 62: return "igemm_lc_kernel<2, 2, 2, 2, 2, 4>";
+        case 63: return "igemm_lc_kernel<2, 2, 2, 2, 2, 5>";
+        case 64: return "igemm_lc_kernel<2, 2, 4, 2, 2, 3>";
+        case 65: return "igemm_lc_kernel<2, 2, 2, 4, 2, 3>";
+        case 66: return "igemm_lc_kernel<2, 2, 2, 1, 2, 6>";
+        case 67: return "igemm_lc_kernel<2, 2, 5, 2, 2, 2>";
+        case 68: return "igemm_lc_kernel<2, 2, 3, 3, 2, 3>";
 #define X(base, WQ, WP, TQ, TP, BK, NST, OCC, ILV) \
         case base: return "igemm_kernel<" #WQ ", " #WP ", " #TQ ", " #TP ", " #BK ", " #NST ", " #OCC ", " #ILV ">";
         LADI_IGEMM_TILES_ALL(X)
@@ -217,6 +239,13 @@ int launch_base(int cfg, const IGemmArgs& a, int batch, hipStream_t st) {
         case 56: return ladi_launch_igemm8(a, 2, 1, batch, st);
         case 57: return ladi_launch_igemm8(a, 5, 1, batch, st);
         case 58: return ladi_launch_igemm8(a, 3, 2, batch, st);
+        case 62: return ladi_launch_igemm_lc(a, 2, 2, 4, batch, st);
+        case 63: return ladi_launch_igemm_lc(a, 2, 2, 5, batch, st);
+        case 64: return ladi_launch_igemm_lc(a, 4, 2, 3, batch, st);
+        case 65: return ladi_launch_igemm_lc(a, 2, 4, 3, batch, st);
+        case 66: return ladi_launch_igemm_lc(a, 2, 1, 6, batch, st);
+        case 67: return ladi_launch_igemm_lc(a, 5, 2, 2, batch, st);
+        case 68: return ladi_launch_igemm_lc(a, 3, 3, 3, batch, st);
         default: return -7;
     }
 }
@@ -309,6 +338,7 @@ static bool cfg_admissible(const IGemmArgs& a, int batch, int c, bool strict) {
         return ladi_linear_xs_eligible(t, batch, ci.tp, ci.bq);
     }
     if (a.ln_gamma && !a.ln_scratch) return false;                    // no scratch: only the fused (X-stationary) form
+    if (is_lc(ci.base) && (a.ups || batch != 1)) return false;        // loader / consumer kernel: no folded upsample, no batched launches
     if (geglu && !ci.geglu_ok) return false;
     if (ci.bk == 64 && ((a.C0 % 64) || (a.C1 % 64))) return false;
     if (ci.split > 1 && (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel)) return false;

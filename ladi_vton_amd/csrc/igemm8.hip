@@ -129,7 +129,6 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IGemmArgs a) {
         nk = max(0, min(sps, nk - start));
         cb = (start / ntap) * BK; tap = start - (start / ntap) * ntap;
     }
-    else if (a.krot) cb = (int)((((unsigned)blockIdx.x >> 3) * 5u) % (unsigned)(Ct / BK)) * BK;   // K rotation, see igemm_kernel.h
     int tdy = tap / a.ksize, tdx = tap - (tap / a.ksize) * a.ksize;
     bool st_valid = nk > 0;            // the K tile being staged exists (tail pieces are issued out of range: zeros, same vmcnt cadence)
     unsigned stbit = st_valid ? (1u << tap) : 0u;   // validity-mask bit of the staged tap (0: every pixel lane out of range)
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IGemmArgs a) {
     };
     auto advance_stage = [&](int kt_staged_next) {
         if (++tdx == a.ksize) { tdx = 0; ++tdy; }
-        if (++tap == ntap) { tap = 0; tdy = 0; tdx = 0; cb += BK; if (cb >= Ct) cb = 0; }
+        if (++tap == ntap) { tap = 0; tdy = 0; tdx = 0; cb += BK; }
         st_valid = kt_staged_next < nk;
         stbit = st_valid ? (1u << tap) : 0u;
     };
@@ -278,8 +277,6 @@ int launch_cfg8(IGemmArgs a, int batch, hipStream_t st) {
     }
     const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
     int blocks = nq * np;
-    static const int krot_env = getenv("LADI_KROT") ? atoi(getenv("LADI_KROT")) : 0;   // experiment switch (round 3)
-    a.krot = (a.splitk > 1) ? 0 : krot_env;
     a.tile_map = 0;
     if (batch == 1 || a.splitk > 1) {
         if (np >= 16) { a.tile_map = 1; blocks = 8 * ((np + 7) / 8) * nq; }

@@ -19,7 +19,6 @@
 #include "common.h"
 #include "kernels.h"
 #include "igemm_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -136,12 +135,6 @@ __global__ __launch_bounds__(64 * WQ * WP, OCC) void igemm_kernel(const IGemmArg
         nk = max(0, min(sps, nk - start));
         cb = (start / ntap) * BK; tap = start - (start / ntap) * ntap;
     }
-    else if (a.krot) {
-        // K rotation: workgroups start the channel-chunk loop at different chunks (and wrap), so that the workgroups of an XCD -- which all
-        // need the SAME weight columns at the same K step -- do not hit the same L2 lines at the same time
-        const int nchunk = Ct / BK;
-        cb = (int)((((unsigned)blockIdx.x >> 3) * 5u) % (unsigned)nchunk) * BK;
-    }
     int tdy = tap / a.ksize, tdx = tap - (tap / a.ksize) * a.ksize;   // window offset of `tap`, advanced incrementally (no per-step division)
 
     // DMA instructions [i0, i1) of the stage described by (tap, cb, tdy, tdx) into ring slot `stage`: indices < RQ are weight rows, the
@@ -183,7 +176,7 @@ __global__ __launch_bounds__(64 * WQ * WP, OCC) void igemm_kernel(const IGemmArg
     };
     auto advance = [&]() {
         if (++tdx == a.ksize) { tdx = 0; ++tdy; }
-        if (++tap == ntap) { tap = 0; tdy = 0; tdx = 0; cb += BK; if (cb >= Ct) cb = 0; }
+        if (++tap == ntap) { tap = 0; tdy = 0; tdx = 0; cb += BK; }
     };
     constexpr int L = RQ + RP;  // DMA instructions per stage per wave
     auto issue = [&](int stage) { issue_part(stage, 0, L); advance(); };
@@ -272,8 +265,6 @@ int launch_cfg(IGemmArgs a, int batch, hipStream_t st) {
     }
     const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
     int blocks = nq * np;
-    static const int krot_env = getenv("LADI_KROT") ? atoi(getenv("LADI_KROT")) : 0;   // experiment switch (round 3)
-    a.krot = (a.splitk > 1) ? 0 : krot_env;
     a.tile_map = 0;
     if (batch == 1 || a.splitk > 1) {
         if (np >= 16) { a.tile_map = 1; blocks = 8 * ((np + 7) / 8) * nq; }

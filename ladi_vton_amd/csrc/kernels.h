@@ -19,6 +19,9 @@ size_t ladi_igemm_splitk_ws_bytes(const IGemmArgs& a, int batch);
 // ladi_launch_igemm, which is the only caller
 int ladi_launch_igemm8(const IGemmArgs& a, int tq, int tp, int batch, hipStream_t st);
 
+// ---- igemm_lc.hip: loader / consumer kernel, consumer wave tile (tq*32 channels) x (tp*32 pixels) on a 2 x 2 consumer grid, nst-deep ring
+int ladi_launch_igemm_lc(const IGemmArgs& a, int tq, int tp, int nst, int batch, hipStream_t st);
+
 // ---- linear_xs.hip: X-stationary kernel for 1x1 layers with K = 320 / 640 (reached through ladi_launch_igemm cfg 23..27)
 bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs);
 int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st);
@@ -142,6 +145,27 @@ int ladi_launch_gather_rows(const h16* src, const int* rows, int n, int H, h16* 
 int ladi_launch_post_quant(const float* lat, const float* pq, float inv_sf, int n, h16* dst, int ld, hipStream_t st);
 int ladi_launch_lat_nchw_to_pix(const float* src, int B, int hw, float scale, float* dst, hipStream_t st);
 int ladi_launch_lat_pix_to_nchw(const float* src, int B, int hw, float* dst, hipStream_t st);
+
+// ---- f32path.hip: fp32 kernels of the warping module (fp32 NHWC activations, fp32 weights, v_mfma_f32_32x32x2_f32)
+struct ConvF32Args {
+    const float* src0; const float* src1;   // up to two NHWC fp32 sources concatenated along channels
+    int C0, C1, ld0, ld1;                   // channels (multiples of 8) and row strides (multiples of 4) of each source
+    int Hs, Ws, Ho, Wo, P;                  // source / output spatial size per sample, output pixels = n * Ho * Wo
+    int ksize, stride, pad;
+    const float* W; int Q, K, ldw;          // [Q][ksize*ksize*(C0+C1)] tap-major / channel-minor (ldw = 0 -> K)
+    long long bs_src0, bs_w, bs_out;        // batching over grid.z (element strides)
+    const float* bias; int act;             // fp32 bias [Q] or null; LADI_ACT_NONE / RELU / TANH / SILU
+    float* out; int ldo;
+};
+int ladi_launch_conv_f32(const ConvF32Args& a, int batch, hipStream_t st);
+int ladi_launch_nchw_to_nhwc_f32(const void* src, int in_f32, int n, int C, int H, int W, float* dst, int ld, hipStream_t st);
+int ladi_launch_nhwc_to_nchw_f32(const float* src, int ld, int n, int C, int H, int W, void* dst, int out_f32, hipStream_t st);
+int ladi_launch_channel_affine_f32(float* x, int ld, size_t n_pix, int C, const float* scale, const float* shift, hipStream_t st);
+int ladi_launch_l2norm_rows_f32(float* x, int ld, int rows, int C, hipStream_t st);
+int ladi_launch_gather_rows_f32(const float* src, const int* rows, int n, int H, float* dst, hipStream_t st);
+int ladi_launch_maxpool2_f32(const float* src, int lds_, int n, int H, int W, int C, float* dst, int ldd, hipStream_t st);
+int ladi_launch_upsample2x_bilinear_ac_f32(const float* src, int lds_, int n, int H, int W, int C, float* dst, int ldd, hipStream_t st);
+int ladi_launch_linear_f32(const float* x, int ldx, const float* W, const float* b, int M, int N, int K, int act, float* out, int ldo, hipStream_t st);
 
 // ---- igemm per-launch timing hooks (HIP events on the launch stream); see igemm.hip
 void ladi_igemm_profile_enable(int on);

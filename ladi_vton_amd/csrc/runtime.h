@@ -226,27 +226,47 @@ struct VisionEncoder {
     int forward(const void* pixels, int in_f32, int B, h16* out_hidden, h16* out_pooled, hipStream_t st);
 };
 
+// ---- fp32 path of the warping module (runtime_f32.cpp, f32path.hip): src/inference.py:253,264 call both networks on fp32 tensors
+struct ActF { float* p = nullptr; int n = 0, h = 0, w = 0, c = 0, ld = 0; size_t pixels() const { return (size_t)n * h * w; } };
+struct DConvF {   // fp32 weights [cout][k*k][cin_pad] (cin padded to a multiple of 8), fp32 bias or null
+    float* w = nullptr; float* b = nullptr;
+    int cin = 0, cin_pad = 0, cout = 0, k = 1;
+    int K() const { return k * k * cin_pad; }
+};
+DConvF load_conv_f32(DevPool& pool, const HostTensor& w, const HostTensor* bias);
+ActF new_act_f32(Ctx& c, int n, int h, int w, int cc);
+ActF conv2d_f32(Ctx& c, const DConvF& cv, const ActF& x, const ActF* x2, int stride, int pad, int act);
+// conv (+ optional own bias) followed by an inference-mode BatchNorm, folded on the host in fp32: w' = w * s, b' = (b - mean) * s + beta
+void fold_conv_bn(const WeightStore& ws, const std::string& conv, const std::string& bn, float eps, HostTensor& fw, HostTensor& fb);
+
 // Refinement UNet of the warping module (first half): src/models/UNet.py UNetVanilla(24, 3, bilinear=True) as
 // instantiated by hubconf.py:57 and called at src/inference.py:264.  BatchNorm (inference mode) is folded into the bias-free convs.
 struct RefineCfg { int in_ch = 24, out_ch = 3, base = 64; float bn_eps = 1e-5f; };
 struct DoubleConvW { DConv c1, c2; };
+struct DoubleConvWF { DConvF c1, c2; };
 struct Refine {
     RefineCfg cfg; DevPool pool;
     DoubleConvW inc, down[4], up[4]; DConv outc;
+    DoubleConvWF incf, downf[4], upf[4]; DConvF outcf;      // fp32 copies (fp32 callers)
     Arena arena;
     void load(const RefineCfg& c, const WeightStore& ws);
-    // x [B, in_ch, H, W] NCHW fp32/fp16 (device) -> out [B, out_ch, H, W] NCHW fp32/fp16; H, W multiples of 16
+    // x [B, in_ch, H, W] NCHW fp32/fp16 (device) -> out [B, out_ch, H, W] NCHW fp32/fp16; H, W multiples of 16.  fp32 input runs the
+    // network in fp32 (weights, activations, accumulation: inference.py:264), fp16 input in fp16 storage / fp32 accumulation
     int forward(const void* x, int in_f32, int B, int H, int W, void* out, int out_f32, hipStream_t st);
+    int forward_f32(const void* x, int B, int H, int W, void* out, int out_f32, hipStream_t st);
 };
 
 // TPS geometric-matching network of the warping module (second half): src/models/ConvNet_TPS.py ConvNet_TPS as
 // instantiated by hubconf.py:56 (256x192, input_nc = 21, n_layer = 3) and called at src/inference.py:253
 struct TpsCfg { int height = 256, width = 192, input_nc = 21, n_layers = 3, grid = 5, ngf = 64; float bn_eps = 1e-5f; };
 struct TpsExtract { std::vector<DConv> conv; std::vector<float*> bn_scale, bn_shift; };   // conv i -> ReLU -> (BatchNorm i, except after the last)
+struct TpsExtractF { std::vector<DConvF> conv; };
 struct Tps {
     TpsCfg cfg; DevPool pool;
     TpsExtract ea, eb;
     DConv reg[4]; DConv lin;          // regression convs (BatchNorm folded) and the control-point linear (columns permuted to NHWC order)
+    TpsExtractF eaf, ebf; DConvF regf[4]; float* linf_w = nullptr; float* linf_b = nullptr;   // fp32 copies (fp32 callers; bn_scale / bn_shift shared)
+    int forward_f32(const void* a, const void* b, int B, float* grid, float* coor, hipStream_t st);
     float* d_inv = nullptr; float* d_ctrl = nullptr;   // TPSGridGen inverse kernel [(N+3)^2], target control points [N][2]
     int* d_perm = nullptr; int perm_cap = 0;           // correlation row order of feature A (column-major positions)
     Arena arena;

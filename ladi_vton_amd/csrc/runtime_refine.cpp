@@ -38,6 +38,13 @@ DoubleConvW load_double(DevPool& pool, const WeightStore& ws, const std::string&
     d.c2 = load_conv_bn(pool, ws, p + ".double_conv.3", p + ".double_conv.4", eps);
     return d;
 }
+DoubleConvWF load_double_f32(DevPool& pool, const WeightStore& ws, const std::string& p, float eps) {
+    DoubleConvWF d;
+    HostTensor fw, fb;
+    fold_conv_bn(ws, p + ".double_conv.0", p + ".double_conv.1", eps, fw, fb); d.c1 = load_conv_f32(pool, fw, &fb);
+    fold_conv_bn(ws, p + ".double_conv.3", p + ".double_conv.4", eps, fw, fb); d.c2 = load_conv_f32(pool, fw, &fb);
+    return d;
+}
 
 Act double_conv(Ctx& c, const DoubleConvW& d, const Act& x, const Act* x2) {
     ConvOpt o; o.act = LADI_ACT_RELU;
@@ -66,11 +73,16 @@ void Refine::load(const RefineCfg& c, const WeightStore& ws) {
     for (int i = 0; i < 4; ++i) down[i] = load_double(pool, ws, "down" + std::to_string(i + 1) + ".maxpool_conv.1", c.bn_eps);
     for (int i = 0; i < 4; ++i) up[i] = load_double(pool, ws, "up" + std::to_string(i + 1) + ".conv", c.bn_eps);
     outc = load_conv(pool, ws, "outc.conv");
+    incf = load_double_f32(pool, ws, "inc", c.bn_eps);
+    for (int i = 0; i < 4; ++i) downf[i] = load_double_f32(pool, ws, "down" + std::to_string(i + 1) + ".maxpool_conv.1", c.bn_eps);
+    for (int i = 0; i < 4; ++i) upf[i] = load_double_f32(pool, ws, "up" + std::to_string(i + 1) + ".conv", c.bn_eps);
+    outcf = load_conv_f32(pool, ws.get("outc.conv.weight"), ws.has("outc.conv.bias") ? &ws.get("outc.conv.bias") : nullptr);
     if (inc.c1.cin != c.in_ch || outc.cout != c.out_ch) throw std::runtime_error("refinement UNet: channel counts do not match the config");
 }
 
 int Refine::forward(const void* x, int in_f32, int B, int H, int W, void* out, int out_f32, hipStream_t st) {
     if (B <= 0 || H <= 0 || W <= 0 || (H % 16) || (W % 16)) { set_error("refinement UNet: H and W must be positive multiples of 16"); return -1; }
+    if (in_f32) return forward_f32(x, B, H, W, out, out_f32, st);      // fp32 caller (inference.py:264): fp32 network (runtime_f32.cpp)
     for (int pass = 0; pass < 2; ++pass) {
         arena.dry = (pass == 0);
         if (pass == 1) arena.reserve(arena.peak);

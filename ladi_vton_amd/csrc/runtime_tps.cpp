@@ -43,11 +43,12 @@ DConv conv_bn_folded(DevPool& pool, const WeightStore& ws, const std::string& co
     return load_conv(pool, t, "f");
 }
 
-void load_extract(DevPool& pool, const WeightStore& ws, const std::string& p, int n_layers, float eps, TpsExtract& e) {
+void load_extract(DevPool& pool, const WeightStore& ws, const std::string& p, int n_layers, float eps, TpsExtract& e, TpsExtractF& ef) {
     const int nconv = n_layers + 3;                       // (1 + n_layers) stride-2 convs + two 3x3 convs
     int idx = 0;
     for (int i = 0; i < nconv; ++i) {
         e.conv.push_back(load_conv(pool, ws, p + ".model." + std::to_string(idx)));
+        ef.conv.push_back(load_conv_f32(pool, ws.get(p + ".model." + std::to_string(idx) + ".weight"), &ws.get(p + ".model." + std::to_string(idx) + ".bias")));
         if (i + 1 < nconv) {
             float *s = nullptr, *t = nullptr;
             bn_affine(pool, ws, p + ".model." + std::to_string(idx + 2), eps, s, t);
@@ -81,10 +82,15 @@ std::vector<double> invert(std::vector<double> a, int n) {
 void Tps::load(const TpsCfg& c, const WeightStore& ws) {
     cfg = c;
     if ((c.height % 64) || (c.width % 64) || c.grid * c.grid > 32) throw std::runtime_error("TPS: height / width must be multiples of 64, grid <= 5");
-    load_extract(pool, ws, "extractionA", c.n_layers, c.bn_eps, ea);
-    load_extract(pool, ws, "extractionB", c.n_layers, c.bn_eps, eb);
+    load_extract(pool, ws, "extractionA", c.n_layers, c.bn_eps, ea, eaf);
+    load_extract(pool, ws, "extractionB", c.n_layers, c.bn_eps, eb, ebf);
     const std::string r = "loc_net.regression.conv.";
-    for (int i = 0; i < 4; ++i) reg[i] = conv_bn_folded(pool, ws, r + std::to_string(3 * i), r + std::to_string(3 * i + 1), c.bn_eps);
+    for (int i = 0; i < 4; ++i) {
+        reg[i] = conv_bn_folded(pool, ws, r + std::to_string(3 * i), r + std::to_string(3 * i + 1), c.bn_eps);
+        HostTensor fw, fb;
+        fold_conv_bn(ws, r + std::to_string(3 * i), r + std::to_string(3 * i + 1), c.bn_eps, fw, fb);
+        regf[i] = load_conv_f32(pool, fw, &fb);
+    }
     {   // linear over flatten(NCHW [64, h, w]) -> columns re-ordered to our NHWC flatten ((h, w), c)
         const HostTensor& w = ws.get("loc_net.regression.linear.weight");
         const HostTensor& b = ws.get("loc_net.regression.linear.bias");
@@ -97,6 +103,7 @@ void Tps::load(const TpsCfg& c, const WeightStore& ws) {
                     for (int x = 0; x < wd; ++x)
                         p[((size_t)o * h * wd + (size_t)y * wd + x) * ch + cc] = w.data[((size_t)o * ch + cc) * h * wd + (size_t)y * wd + x];
         lin.w = pool.upload_h16(p); lin.b = pool.upload_h16(b.data); lin.cin = lin.cin_pad = ch * h * wd; lin.cout = nout; lin.k = 1;
+        linf_w = pool.upload_f32(p); linf_b = pool.upload_f32(b.data);
     }
     // TPSGridGen.__init__ (:132-170): control lattice of range 0.9 (ConvNet_TPS.__init__ :291-306), padded kernel matrix, its inverse
     const int G = c.grid, N = G * G, M = N + 3;
@@ -141,6 +148,8 @@ int Tps::forward(const void* a, const void* b, int in_f32, int B, float* grid, f
         if (hipMemcpy(d_perm, p.data(), p.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { set_error("TPS: H2D"); return -1; }
         perm_cap = B * hw;
     }
+    // fp32 tensors from the caller (what src/inference.py:253 passes): the whole network runs in fp32 (runtime_f32.cpp)
+    if (in_f32) return forward_f32(a, b, B, grid, coor, st);
     for (int pass = 0; pass < 2; ++pass) {
         arena.dry = (pass == 0);
         if (pass == 1) arena.reserve(arena.peak);

@@ -71,6 +71,7 @@ def main():
     make_text_golden(g)
     make_vision_golden(g)
     make_warp_golden()
+    make_warp_composed_golden()
     make_wiring_golden()
     make_wiring_lms_golden()
     make_dataset_golden()
@@ -150,6 +151,72 @@ def make_warp_golden():
         refined = ref(refine_in)
     save_file({"corr_sample": corr[:, :, ::4, ::4].contiguous(), "coor": coor.contiguous(), "grid": grid.half().contiguous(),
                "warped": warped.half().contiguous(), "refined": refined.contiguous()}, os.path.join(OUT, "warp_modules.safetensors"))
+
+
+def warp_composed_inputs(H=384, W=288):
+    """deterministic inputs of the composed-warp fixture: cloth [1,3,H,W], im_mask [1,3,H,W], pose_map [1,18,H,W] in [-1, 1]"""
+    g = torch.Generator().manual_seed(78)
+    F = torch.nn.functional
+    def smooth(c):
+        return F.interpolate(torch.rand((1, c, H // 8, W // 8), generator=g) * 2 - 1, size=(H, W), mode="bilinear", align_corners=False)
+    return smooth(3), smooth(3), smooth(18)
+
+
+def warp_composed_weights(damp):
+    """synthetic checkpoint of the warping module; damp scales the control-point regression (0.2 keeps tanh in its linear range, where an
+    error in the regression input shows up undiminished; 1.0 = the raw synthetic weights, tanh partly saturated)"""
+    from ladi_vton_amd import configs as C
+    tsd = C.synth_state_dict(C.tps_shapes(C.TPS_FULL), "tps.", fp16_round=False)
+    tsd["loc_net.regression.linear.weight"] = tsd["loc_net.regression.linear.weight"] * damp
+    rsd = C.synth_state_dict(C.refine_shapes(C.REFINE_FULL), "refine.", fp16_round=False)
+    return tsd, rsd
+
+
+def make_warp_composed_golden():
+    """tests/golden/warp_composed.safetensors: the warping stage of src/inference.py:239-266 END TO END on the REAL reference modules --
+    antialiased bilinear down-sampling of cloth / im_mask / pose_map to 256x192, cat([low_im_mask, low_pose_map]), ConvNet_TPS (through its
+    sub-modules: its forward() hard-codes .cuda()), antialiased up-sampling of the grid, F.grid_sample(padding_mode='border'),
+    cat([im_mask, pose_map, warped_cloth]) -> UNetVanilla -> clamp(-1, 1) -- for the damped (0.2) and the raw (1.0) regression weights.
+    torchvision.transforms.functional.resize(tensor, size, BILINEAR, antialias=True) is torch's interpolate(mode='bilinear',
+    antialias=True, align_corners=False) (torchvision/transforms/_functional_tensor.py resize); torchvision is not installed here, so that
+    call is made directly.  The reference up-samples the grid to its fixed (512, 384); here to the size of the fixture's cloth."""
+    import contextlib
+    import io
+    sys.path.insert(0, REF)
+    from src.models.ConvNet_TPS import ConvNet_TPS
+    from src.models.UNet import UNetVanilla
+    F = torch.nn.functional
+
+    def resize(x, size):
+        return F.interpolate(x, size=size, mode="bilinear", antialias=True, align_corners=False)
+
+    cloth, im_mask, pose_map = warp_composed_inputs()
+    H, W = cloth.shape[-2:]
+    blob = {}
+    for tag, damp in (("", 0.2), ("_raw", 1.0)):
+        tsd, rsd = warp_composed_weights(damp)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tps = ConvNet_TPS(256, 192, 21, 3).eval()
+        refinement = UNetVanilla(n_channels=24, n_classes=3, bilinear=True).eval()
+        missing, unexpected = tps.load_state_dict(tsd, strict=False)
+        assert not unexpected and all(k.startswith("gridGen.") or k.endswith("num_batches_tracked") for k in missing)
+        missing, unexpected = refinement.load_state_dict(rsd, strict=False)
+        assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+        with torch.no_grad():
+            low_cloth = resize(cloth, (256, 192))                                                    # inference.py:242-244
+            agnostic = torch.cat([resize(im_mask, (256, 192)), resize(pose_map, (256, 192))], 1)     # :245-251
+            fa = tps.l2norm(tps.extractionA(low_cloth.to(torch.float32)))                            # :253 -> ConvNet_TPS.py:318-334
+            fb = tps.l2norm(tps.extractionB(agnostic.to(torch.float32)))
+            theta = tps.loc_net.regression(tps.correlation(fa, fb)).view(1, -1, 2)
+            low_grid = tps.gridGen(theta).view(1, 256, 192, 2)
+            highres_grid = resize(low_grid.permute(0, 3, 1, 2), (H, W)).permute(0, 2, 3, 1)           # :256-259
+            warped = F.grid_sample(cloth.to(torch.float32), highres_grid.to(torch.float32), padding_mode="border")   # :260
+            refined = refinement(torch.cat([im_mask, pose_map, warped], 1).to(torch.float32)).clamp(-1, 1)          # :263-265
+        blob["theta" + tag] = theta.contiguous()
+        blob["low_grid_sub" + tag] = low_grid[:, ::4, ::4].contiguous()
+        blob["warped_sub" + tag] = warped[:, :, ::4, ::4].contiguous()
+        blob["refined" + tag] = refined.half().contiguous()
+    save_file(blob, os.path.join(OUT, "warp_composed.safetensors"))
 
 
 def wiring_inputs(B=2, H=128, W=64, L=8, D=128):
@@ -374,4 +441,7 @@ def make_text_golden(g):
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "warp_composed":      # only this fixture (the others stay byte-identical)
+        make_warp_composed_golden()
+    else:
+        main()

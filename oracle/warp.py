@@ -122,3 +122,20 @@ def refinement_forward(sd, x):
     x = _up(sd, "up3", x, x2)
     x = _up(sd, "up4", x, x1)
     return F.conv2d(x, sd["outc.conv.weight"], sd["outc.conv.bias"])
+
+
+def resize_antialias(x, size):
+    """torchvision.transforms.functional.resize(x, size, BILINEAR, antialias=True) for tensors (src/inference.py:242-258)"""
+    return F.interpolate(x, size=size, mode="bilinear", antialias=True, align_corners=False)
+
+
+def warp_cloth(tsd, tcfg, rsd, cloth, im_mask, pose_map, low_size=(256, 192)):
+    """the composed warping stage, src/inference.py:239-266 -> (refined warped cloth [B,3,H,W] clamped to [-1,1], theta, low_grid, warped)"""
+    H, W = cloth.shape[-2:]
+    low_cloth = resize_antialias(cloth, low_size)
+    agnostic = torch.cat([resize_antialias(im_mask, low_size), resize_antialias(pose_map, low_size)], 1)
+    low_grid, theta = tps_forward(tsd, tcfg, low_cloth.float(), agnostic.float())
+    grid = resize_antialias(low_grid.permute(0, 3, 1, 2), (H, W)).permute(0, 2, 3, 1)
+    warped = warp(cloth.float(), grid.float())
+    refined = refinement_forward(rsd, torch.cat([im_mask, pose_map, warped], 1).float()).clamp(-1, 1)
+    return refined, theta, low_grid, warped

@@ -211,6 +211,29 @@ def test_warp_oracle_matches_reference_modules_golden():
     assert grid.shape == (1, 256, 192, 2) and refined.shape == (1, 3, 64, 48)
 
 
+@pytest.mark.parametrize("tag,damp", [("", 0.2), ("_raw", 1.0)])
+def test_warp_oracle_matches_composed_reference_golden(tag, damp):
+    """the COMPOSED warping stage (src/inference.py:239-266: antialiased resizes -> TPS -> grid up-sampling -> border grid_sample -> concat
+    -> refinement UNet -> clamp) of the oracle against the fixture made from the REAL reference modules, for the damped (tanh in its linear
+    range) and the raw synthetic regression weights"""
+    import warnings
+    from oracle import warp as W
+    from oracle.make_golden import warp_composed_inputs, warp_composed_weights
+    c = load_file(os.path.join(GOLD, "warp_composed.safetensors"))
+    tsd, rsd = warp_composed_weights(damp)
+    cloth, im_mask, pose_map = warp_composed_inputs()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        refined, theta, low_grid, warped = W.warp_cloth(tsd, C.TPS_FULL, rsd, cloth, im_mask, pose_map)
+    assert torch.allclose(theta, c["theta" + tag], atol=1e-5, rtol=1e-4)
+    assert torch.allclose(low_grid[:, ::4, ::4], c["low_grid_sub" + tag], atol=2e-5)
+    assert torch.allclose(warped[:, :, ::4, ::4], c["warped_sub" + tag], atol=1e-4)
+    assert torch.allclose(refined, c["refined" + tag].float(), atol=2e-3)            # fixture stored as fp16
+    assert refined.shape == (1, 3, 384, 288) and float(refined.abs().max()) <= 1.0
+    if damp == 0.2:
+        assert theta.abs().max() < 0.999                                              # tanh not saturated: errors upstream are not hidden
+
+
 def test_mask_features_progressive_equals_strided():
     """SURVEY.md §3.3: the progressive nearest chain equals mask[..., ::s, ::s] (what the native kernels implement)"""
     g = torch.Generator().manual_seed(0)
