@@ -86,6 +86,13 @@ int ladi_vae_encode(ladi_vae* v, const void* x_dev, int dtype, int B, int H, int
  * NHWC fp16 EMASC outputs (idx1..5 order) -> sample [B,3,8h,8w] NCHW (out_dtype), NOT post-processed. */
 int ladi_vae_decode(ladi_vae* v, const float* z_dev, int B, int h, int w, const void* const* skips_dev, void* sample_dev,
                     int out_dtype, void* stream);
+/* fp16-range guard of the decoder (SD VAE activations can leave the fp16 range with real checkpoints; the reference
+ * runs src/models/AutoencoderKL.py:159-188 in whatever dtype the caller picked).  The decoder's residual stream is stored multiplied by
+ * 2^-shift (GroupNorm is scale invariant, every branch into the stream is scaled in its producer's epilogue): the same function with
+ * 2^shift more head-room.  shift = -1 (default): automatic -- decode at shift 0 and, if a GroupNorm saw non-finite statistics, again at 4,
+ * then 8 (an error after that); shift >= 0: fixed.  ladi_vae_last_range_shift reports what the last decode used. */
+int ladi_vae_set_range_shift(ladi_vae* v, int shift);
+int ladi_vae_last_range_shift(const ladi_vae* v);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * EMASC — replaces src/models/emasc.py EMASC.forward (:37-40); mask_features (src/utils/data_utils.py:4-16) can be
@@ -258,7 +265,7 @@ typedef struct {
     const void* bias; int bias_per_pixel; const float* rowadd; const int* rowadd_idx; int rowadd_stride; int act; float out_scale;
     const void* res0; const void* res1; int ldr0, ldr1; const void* mask; void* out; int ldo; int out_f32;
     float* stats; int stats_groups; int splitk, tile_map /* both ignored: set by the launcher */;
-    const void* ln_gamma; const void* ln_beta; float ln_eps; int ln_pad_; void* ln_scratch;
+    const void* ln_gamma; const void* ln_beta; float ln_eps; float bias_mul /* multiplier of bias, 0 = 1 */; void* ln_scratch;
     /* optional LayerNorm of the pixel operand (single source, 1x1): fused into the X-stationary linear kernel where the tuner finds that
        faster, else run as its own kernel into ln_scratch ([P][C0] fp16, caller-provided; null = only the fused form is admissible) */
 } ladi_igemm_desc;

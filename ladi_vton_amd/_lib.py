@@ -77,7 +77,7 @@ class IGemmDesc(Structure):
                 ("rowadd_stride", c_int), ("act", c_int), ("out_scale", c_float),
                 ("res0", c_void_p), ("res1", c_void_p), ("ldr0", c_int), ("ldr1", c_int), ("mask", c_void_p),
                 ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("stats", c_void_p), ("stats_groups", c_int), ("splitk", c_int), ("tile_map", c_int),
-                ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("ln_pad_", c_int), ("ln_scratch", c_void_p)]
+                ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("bias_mul", c_float), ("ln_scratch", c_void_p)]
 
 
 # every symbol include/ladi_native.h declares: name -> (restype, argtypes)
@@ -126,6 +126,8 @@ SIGNATURES = {
     "ladi_tryon_run": (c_int, [_P, POINTER(TryOnInputs), _P, _P, _P]),
     "ladi_tryon_stage_ms": (c_int, [_P, POINTER(c_float)]),
     "ladi_tryon_set_trace": (c_int, [_P, _P, _P, c_int]),
+    "ladi_vae_set_range_shift": (c_int, [_P, c_int]),
+    "ladi_vae_last_range_shift": (c_int, [_P]),
     "ladi_igemm_set_autotune": (None, [c_int]),
     "ladi_profile_igemm_enable": (None, [c_int]),
     "ladi_profile_igemm_collect": (c_int, [POINTER(ctypes.c_double), c_int]),

@@ -183,13 +183,17 @@ int ladi_vae_encode(ladi_vae* v, const void* x, int dtype, int B, int H, int W, 
             Act xi = c.new_act(B, H, W, 64);
             if (!c.dry()) c.check(ladi_launch_nchw_to_nhwc(x, dtype == LADI_F32, B, 3, H, W, xi.p, 64, st), "nchw_to_nhwc");
             Act feats[5];
+            c.bad = V.d_bad;
             Act mom = V.encode(c, xi, feats);
+            c.bad = nullptr;
             if (c.dry()) return;
             c.check(ladi_launch_nhwc_to_nchw(mom.p, mom.ld, B, 8, H / 8, W / 8, moments, 1, st), "moments");
             if (feats_out)
                 for (int i = 0; i < 5; ++i)
                     if (feats_out[i]) HIP_OK(hipMemcpyAsync(feats_out[i], feats[i].p, feats[i].pixels() * feats[i].c * sizeof(h16), hipMemcpyDeviceToDevice, st));
         });
+        // the encoder's intermediate features feed EMASC at their true scale, so there is no scaled form to fall back to: report instead
+        if (V.overflowed(st)) throw std::runtime_error("VAE encode: activations exceed the fp16 range (non-finite GroupNorm statistics)");
         return 0;
     });
 }
@@ -199,6 +203,7 @@ int ladi_vae_decode(ladi_vae* v, const float* z, int B, int h, int w, const void
     return guarded("ladi_vae_decode", [&]() {
         VAE& V = v->v;
         hipStream_t st = S(stream);
+        (void)V.decode_guarded(st, [&](int shift) {
         run_planned(V.arena, V.stats, V.stats_cap, st, [&](Ctx& c) {
             float* zp = c.alloc_f32((size_t)B * h * w * 4);
             Act zi = c.new_act(B, h, w, 64);
@@ -217,12 +222,20 @@ int ladi_vae_decode(ladi_vae* v, const float* z, int B, int h, int w, const void
                 c.check(ladi_launch_lat_nchw_to_pix(z, B, h * w, 1.0f, zp, st), "z");
                 c.check(ladi_launch_post_quant(zp, V.d_pq, 1.0f, B * h * w, zi.p, 64, st), "post_quant");
             }
-            Act img = V.decode(c, zi, skips_dev ? skips : nullptr);
+            Act img = V.decode(c, zi, skips_dev ? skips : nullptr, shift);
             if (!c.dry()) c.check(ladi_launch_nhwc_to_nchw(img.p, img.ld, B, 3, 8 * h, 8 * w, sample, out_dtype == LADI_F32, st), "sample");
+        });
         });
         return 0;
     });
 }
+
+int ladi_vae_set_range_shift(ladi_vae* v, int shift) {
+    if (!v || shift > 12) { set_error("ladi_vae_set_range_shift: shift must be -1 (automatic) or 0..12"); return -1; }
+    v->v.range_shift = shift < 0 ? -1 : shift;
+    return 0;
+}
+int ladi_vae_last_range_shift(const ladi_vae* v) { return v ? v->v.last_shift : -1; }
 
 // ------------------------------------------------------------------------------------------------ EMASC
 ladi_emasc* ladi_emasc_create(const ladi_emasc_config* cfg, const ladi_weights* ws) {

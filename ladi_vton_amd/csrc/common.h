@@ -108,6 +108,8 @@ struct IGemmArgs {
     // fp16 (null = none).  The X-stationary linear kernel fuses it into its prologue (the wave holds whole rows in registers); every
     // other configuration runs the stand-alone LayerNorm kernel into ln_scratch ([P][C0] fp16) first -- the tuner times both forms
     const h16* ln_gamma; const h16* ln_beta;
-    float ln_eps; int ln_pad_;
+    float ln_eps;
+    float bias_mul;      // multiplier of `bias` (0 means 1): the VAE keeps its residual stream scaled by 2^-k when the fp16 range is tight
+                         // (runtime_vae.cpp); a convolution whose INPUT is the scaled stream then needs bias * 2^-k
     h16* ln_scratch;
 };

@@ -742,3 +742,20 @@ int ladi_launch_grid_sample_border(const void* src, int in_f32, int B, int C, in
                        Ho, Wo, dst, out_f32);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
+
+// dst = src * s (fp16 NHWC rows of C channels; the VAE range guard's scaled copies of the EMASC skips)
+__global__ void scale_h16_kernel(const h16* __restrict__ src, int lds_, h16* __restrict__ dst, int ldd, size_t n_pix, int C8, float s) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pix * C8) return;
+    const size_t p = idx / C8; const int c = (int)(idx % C8) * 8;
+    h16x8 v = *reinterpret_cast<const h16x8*>(src + p * lds_ + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] * s);
+    *reinterpret_cast<h16x8*>(dst + p * ldd + c) = v;
+}
+int ladi_launch_scale_h16(const h16* src, int lds_, h16* dst, int ldd, size_t n_pix, int C, float s, hipStream_t st) {
+    if ((C & 7) || (lds_ & 7) || (ldd & 7)) return -1;
+    const size_t total = n_pix * (C / 8);
+    hipLaunchKernelGGL(scale_h16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, lds_, dst, ldd, n_pix, C / 8, s);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

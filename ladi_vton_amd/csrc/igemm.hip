@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (rowadd && a.rowadd_idx) rowadd += (size_t)(*a.rowadd_idx) * a.rowadd_stride;
     float ssum = 0.f, ssq = 0.f;
     if (c < a.Q) {
-        const float b = (a.bias ? (float)a.bias[c] : 0.f) + (rowadd ? rowadd[c] : 0.f);
+        const float b = (a.bias ? (float)a.bias[c] * (a.bias_mul != 0.f ? a.bias_mul : 1.f) : 0.f) + (rowadd ? rowadd[c] : 0.f);
         for (int r = pl; r < 32; r += 4) {
             const int p = p_base + r;
             if (p >= a.P) break;

@@ -28,6 +28,7 @@ __device__ __forceinline__ void igemm_epilogue_generic(const IGemmArgs& a, f32x1
                                                        const int pt, const int z, const int wave, const int lane) {
     const int wq = wave / WP, wp = wave % WP;
     const int l31 = lane & 31, hh = lane >> 5;
+    const float bmul = a.bias_mul != 0.f ? a.bias_mul : 1.f;
     // ------------------------------------------------------------------------------------------
     // Epilogue: lane owns pixel (col) l31 of each pixel sub-tile and 4-channel groups of each q sub-tile.
     // ------------------------------------------------------------------------------------------
@@ -45,7 +46,7 @@ __device__ __forceinline__ void igemm_epilogue_generic(const IGemmArgs& a, f32x1
         constexpr int j = decltype(Jc)::value;
         pj[j] = p0 + (wp * TP + j) * 32 + l31;
         prow[j] = pj[j] < a.P;
-        pbj[j] = (prow[j] && a.bias && a.bias_per_pixel) ? (float)a.bias[pj[j]] : 0.f;
+        pbj[j] = (prow[j] && a.bias && a.bias_per_pixel) ? (float)a.bias[pj[j]] * bmul : 0.f;
     });
 
     if (a.out_f32) {
@@ -63,7 +64,7 @@ __device__ __forceinline__ void igemm_epilogue_generic(const IGemmArgs& a, f32x1
                         for (int e = 0; e < 4; ++e) {
                             float x = acc[iu][j][4 * g + e];
                             if (a.bias_per_pixel) x += pbj[j];
-                            else if (a.bias && (co + e) < a.Q) x += (float)a.bias[co + e];
+                            else if (a.bias && (co + e) < a.Q) x += (float)a.bias[co + e] * bmul;
                             v[e] = x * a.out_scale;
                         }
                         float* op = reinterpret_cast<float*>(a.out) + zo + (size_t)pj[j] * a.ldo + co;
@@ -117,10 +118,10 @@ __device__ __forceinline__ void igemm_epilogue_generic(const IGemmArgs& a, f32x1
                     for (int e = 0; e < 4; ++e) {
                         float x = acc[iu][j][4 * g + e];
                         if (a.bias_per_pixel) x += pbj[j];
-                        else if (a.bias && (qw + e) < a.Q) x += (float)a.bias[qw + e];
+                        else if (a.bias && (qw + e) < a.Q) x += (float)a.bias[qw + e] * bmul;
                         if (geglu) {
                             float gg = acc[ig][j][4 * g + e];
-                            if (a.bias && (qw + 32 + e) < a.Q) gg += (float)a.bias[qw + 32 + e];
+                            if (a.bias && (qw + 32 + e) < a.Q) gg += (float)a.bias[qw + 32 + e] * bmul;
                             x = x * gelu_f(gg);
                         } else {
                             if (rowadd && (co + e) < Qout) x += rowadd[co + e];
@@ -235,6 +236,7 @@ __device__ __forceinline__ void igemm_epilogue_fast(const IGemmArgs& a, f32x16 (
     constexpr int NPASS = (32 + RPW - 1) / RPW;
     const int wq = wave / WP, wp = wave % WP;
     const int l31 = lane & 31, hh = lane >> 5;
+    const float bmul = a.bias_mul != 0.f ? a.bias_mul : 1.f;
     const int Qout = GEGLU ? a.Q / 2 : a.Q;
     const size_t zo = (size_t)z * a.bs_out;
     const size_t zr = (size_t)z * a.bs_res;
@@ -249,7 +251,7 @@ __device__ __forceinline__ void igemm_epilogue_fast(const IGemmArgs& a, f32x16 (
             const int q = q0 + c;
             float v = 0.f;
             if (q < a.Q) {
-                if (a.bias && !a.bias_per_pixel) v = (float)a.bias[q];
+                if (a.bias && !a.bias_per_pixel) v = (float)a.bias[q] * bmul;
                 if (!GEGLU && rowadd) v += rowadd[q];
             }
             cadd[c] = v;
@@ -272,7 +274,7 @@ __device__ __forceinline__ void igemm_epilogue_fast(const IGemmArgs& a, f32x16 (
         const int pbase = p0 + (wp * TP + j) * 32;
         // (1) lane = pixel column: per-channel vector / activation, round to fp16, 8-byte LDS writes
         const int pcol = pbase + l31;
-        const float pb = (a.bias && a.bias_per_pixel && pcol < a.P) ? (float)a.bias[pcol] : 0.f;
+        const float pb = (a.bias && a.bias_per_pixel && pcol < a.P) ? (float)a.bias[pcol] * bmul : 0.f;
         // the activation is selected ONCE per sub-tile (wave-uniform switch around the unrolled loops): a per-element `if (act == ...)`
         // chain costs ~20 scalar branches per 4 values, more than all the arithmetic of this epilogue together
         auto step1 = [&](auto ActC) {

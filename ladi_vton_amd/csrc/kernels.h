@@ -32,7 +32,8 @@ int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st);
 int ladi_gn_partial_rows(int n, int HW, int C);   // rows per sample ladi_launch_gn_partial writes
 int ladi_launch_gn_partial(const h16* src, int C, int ld, int n, int HW, float* part, hipStream_t st);
 int ladi_launch_gn_finalize(const float* part0, int C0, int rps0, const float* part1, int C1, int rps1, int n, int HW, int groups,
-                            const h16* gamma, const h16* beta, float eps, float* scale_shift, hipStream_t st);
+                            const h16* gamma, const h16* beta, float eps, float* scale_shift, hipStream_t st, int* bad = nullptr);
+// `bad` (optional, device): set to 1 when a group's statistics are not finite -- an fp16 overflow upstream (VAE range guard)
 // y = act(x * scale + shift) (+ add) over the virtual concat (src0[C0] | src1[C1]): out [n][HW][C0+C1] dense
 int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int C1, int ld1, int n, int HW,
                          const float* scale_shift, int silu, const h16* add, h16* out, hipStream_t st);
@@ -119,6 +120,7 @@ int ladi_launch_image_post(const h16* src, int ld, int n_pix, float* dst, hipStr
 // features[i] *= (1-mask) standalone (mask_features for the module-by-module shim path)
 int ladi_launch_mask_mul(h16* feat, int C, int n_pix, const h16* mask, hipStream_t st);
 int ladi_launch_fill_f32(float* p, size_t n, float v, hipStream_t st);
+int ladi_launch_scale_h16(const h16* src, int lds_, h16* dst, int ldd, size_t n_pix, int C, float s, hipStream_t st);
 // CLIP text embeddings + pseudo-word splice: ids [B][T] (device), first [B] = position of the sentence's first '$' or -1,
 // wemb fp16 [B][nv][H] or null; out [B][T][H] = (token | pseudo-word) embedding + position embedding
 int ladi_launch_text_embed(const int* ids, const int* first, int nv, const h16* tok, const h16* pos, const h16* wemb, int B, int T,

@@ -326,7 +326,7 @@ bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs) {
     if (a.out_f32 || (a.act != LADI_ACT_NONE && !geglu) || a.rowadd || a.bias_per_pixel || a.mask || a.res1 || a.stats) return false;
     if (geglu && res) return false;
     if (res && ((a.ldr0 % 8) || (size_t)a.P * a.ldr0 * 2 >= 0x7FFFFFFFull)) return false;
-    if (a.out_scale != 1.f || a.splitk > 1) return false;
+    if (a.out_scale != 1.f || a.splitk > 1 || (a.bias_mul != 0.f && a.bias_mul != 1.f)) return false;
     const int unit = geglu ? 64 : 32;
     if ((a.Q % unit) || ((a.Q / unit) % qs) || (a.P % (128 * pb))) return false;
     if ((size_t)a.Q * a.K * 2 >= 0x7FFFFFFFull) return false;

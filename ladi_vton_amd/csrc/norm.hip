@@ -72,7 +72,7 @@ constexpr int GNF_MAX_CH = 512;   // channels per block (GPB * gs)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part0, int C0, int rps0,
                                                           const float* __restrict__ part1, int C1, int rps1, int HW, int groups,
                                                           int gpb, const h16* __restrict__ gamma, const h16* __restrict__ beta,
-                                                          float eps, float* __restrict__ scale_shift) {
+                                                          float eps, float* __restrict__ scale_shift, int* __restrict__ bad) {
     __shared__ float rsum[256], rsq[256];
     __shared__ float csum[GNF_MAX_CH], csq[GNF_MAX_CH];
     __shared__ float gmean[16], grstd[16];
@@ -112,6 +112,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         const float mean = s * inv;
         const float var = fmaxf(q * inv - mean * mean, 0.f);
         gmean[tid] = mean; grstd[tid] = rsqrtf(var + eps);
+        // fp16-range guard: an activation that overflowed to inf (or a NaN behind it) shows up in the statistics of the next GroupNorm
+        if (bad && !(fabsf(s) <= 3.0e38f && q <= 3.0e38f)) *bad = 1;
     }
     __syncthreads();
     for (int cc = tid; cc < nch; cc += 256) {
@@ -302,7 +304,7 @@ int ladi_launch_gn_partial(const h16* src, int C, int ld, int n, int HW, float* 
 }
 
 int ladi_launch_gn_finalize(const float* part0, int C0, int rps0, const float* part1, int C1, int rps1, int n, int HW, int groups,
-                            const h16* gamma, const h16* beta, float eps, float* scale_shift, hipStream_t st) {
+                            const h16* gamma, const h16* beta, float eps, float* scale_shift, hipStream_t st, int* bad) {
     const int Ct = C0 + C1;
     if (groups > 64 || (Ct % groups) || Ct > GN_MAX_C) return -1;
     const int gs = Ct / groups;
@@ -310,7 +312,7 @@ int ladi_launch_gn_finalize(const float* part0, int C0, int rps0, const float* p
     while (gpb > 1 && gpb * gs > GNF_MAX_CH) gpb >>= 1;
     if (gpb * gs > GNF_MAX_CH || gpb > 16) return -1;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(n, (groups + gpb - 1) / gpb), dim3(256), 0, st, part0, C0, rps0, part1, C1, rps1, HW,
-                       groups, gpb, gamma, beta, eps, scale_shift);
+                       groups, gpb, gamma, beta, eps, scale_shift, bad);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 

@@ -7,6 +7,7 @@
 #include <vector>
 #include <unordered_map>
 #include <memory>
+#include <stdexcept>
 
 namespace ladi {
 
@@ -63,6 +64,7 @@ struct Ctx {
     float* stats = nullptr;  // GroupNorm statistics arena (floats), zeroed at forward start
     size_t stats_off = 0, stats_cap = 0, stats_peak = 0;
     int err = 0;
+    int* bad = nullptr;      // optional device flag: set by a GroupNorm whose input statistics are not finite (fp16 overflow upstream)
     bool dry() const { return ar->dry; }
     h16* alloc_h16(size_t elems) { return reinterpret_cast<h16*>(ar->alloc(elems * sizeof(h16))); }
     float* alloc_f32(size_t elems) { return reinterpret_cast<float*>(ar->alloc(elems * sizeof(float))); }
@@ -85,6 +87,7 @@ struct ConvOpt {
     const Act* res0 = nullptr; const Act* res1 = nullptr;
     const h16* mask = nullptr;
     float out_scale = 1.f;
+    float bias_mul = 0.f;    // multiplier of the bias (0 = 1), see IGemmArgs::bias_mul
     int out_ld = 0;          // 0 -> cout (GEGLU: cout/2)
     int cfg = 0;             // igemm tile config override
     bool stats = false;      // also produce per-channel partial statistics of the output (for a consuming GroupNorm)
@@ -168,14 +171,38 @@ struct VAE {
     DConv d_conv_in, d_conv_out; DNorm d_norm_out; float pq_w[16]; float pq_b[4]; float* d_pq = nullptr;  // post_quant 4x4 on device
     std::vector<ResBlock> d_res; DConv d_up[3]; ResBlock d_mid[2]; VAEAttn d_attn;
     Arena arena; float* stats = nullptr; size_t stats_cap = 0;
+    // fp16-range guard of the decoder (with the released weights the decoder's residual stream can exceed 65504).
+    // The stream is stored multiplied by 2^-range_shift; GroupNorm is scale invariant (its eps is scaled by 4^-shift), every branch that
+    // feeds the stream is scaled in its producer's epilogue, so the result is the same function with 2^shift more head-room.
+    // range_shift < 0 = automatic: run at shift 0, and if a GroupNorm saw non-finite statistics (d_bad) re-run at 4, then 8.
+    int range_shift = -1; int last_shift = 0; int* d_bad = nullptr;
 
     void load(const VAECfg& c, const WeightStore& ws);
     // x: [n,H,W,64] padded NHWC image. Returns moments Act [n,h,w,8]; feats[0..4] = encoder features idx1..5 (views)
     Act encode(Ctx& c, const Act& x, Act feats[5]);
-    // z: [n,h,w,64] padded NHWC (post_quant already applied); skips[0..4] = EMASC outputs for idx1..5 or null
-    Act decode(Ctx& c, const Act& z, const Act* skips);
+    // z: [n,h,w,64] padded NHWC (post_quant already applied); skips[0..4] = EMASC outputs for idx1..5 or null; shift: see range_shift
+    Act decode(Ctx& c, const Act& z, const Act* skips, int shift = 0);
+    // decode under the range guard: runs `body(shift)` (which must call decode(c, z, skips, shift) and emit the outputs) once, or again
+    // with a larger shift when the overflow flag came back set; returns the shift that was used.  Synchronises the stream once.
+    template <typename Body> int decode_guarded(hipStream_t st, Body&& body);
+    bool overflowed(hipStream_t st);     // reads (and clears) d_bad; synchronises `st`
     ~VAE();
 };
+
+template <typename Body>
+int VAE::decode_guarded(hipStream_t st, Body&& body) {
+    const int fixed = range_shift;
+    const int tries[3] = {0, 4, 8};
+    for (int t = 0; t < 3; ++t) {
+        const int sh = fixed >= 0 ? fixed : tries[t];
+        body(sh);
+        last_shift = sh;
+        if (!overflowed(st)) return sh;
+        if (fixed >= 0) break;
+    }
+    throw std::runtime_error("VAE decode: activations exceed the fp16 range (non-finite GroupNorm statistics) at range shift " +
+                             std::to_string(last_shift));
+}
 
 struct EMASCCfg { int n = 5; int in_ch[8] = {128, 128, 128, 256, 512}; int out_ch[8] = {128, 256, 512, 512, 512}; };
 struct EMASC {

@@ -223,7 +223,7 @@ Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& 
     a.ksize = cv.k; a.stride = o.stride; a.pad = pad; a.ups = o.ups;
     a.W = cv.w; a.Q = cv.cout; a.K = cv.K(); a.ldw = 0;
     a.bias = cv.b; a.rowadd = o.rowadd; a.rowadd_idx = o.rowadd_idx; a.rowadd_stride = o.rowadd_stride;
-    a.act = o.act; a.out_scale = o.out_scale;
+    a.act = o.act; a.out_scale = o.out_scale; a.bias_mul = o.bias_mul;
     if (o.res0) { a.res0 = o.res0->p; a.ldr0 = o.res0->ld; }
     if (o.res1) { a.res1 = o.res1->p; a.ldr1 = o.res1->ld; }
     a.mask = o.mask;
@@ -264,7 +264,7 @@ Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups,
         }
     }
     if (c.dry()) return out;
-    c.check(ladi_launch_gn_finalize(part[0], C0, rps[0], part[1], C1, rps[1], x.n, HW, groups, nm.g, nm.b, eps, ss, c.st), "gn_finalize");
+    c.check(ladi_launch_gn_finalize(part[0], C0, rps[0], part[1], C1, rps[1], x.n, HW, groups, nm.g, nm.b, eps, ss, c.st, c.bad), "gn_finalize");
     c.check(ladi_launch_gn_apply(x.p, C0, x.ld, x2 ? x2->p : nullptr, C1, x2 ? x2->ld : 0, x.n, HW, ss, silu, add ? add->p : nullptr, out.p,
                                  c.st), "gn_apply");
     return out;

@@ -204,10 +204,21 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
                     if (stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
                     c.check(ladi_launch_post_quant(latents, vae->d_pq, 1.0f / vae->cfg.scaling_factor, B * hw, z.p, 64, st), "post_quant");
                 }
-                c.stats_off = 0;
-                Act img = vae->decode(c, z, use_emasc ? skips : nullptr);
-                if (!c.dry()) {
-                    c.check(ladi_launch_image_post(img.p, img.ld, B * H * W, images_out, st), "image_post");
+                // decode under the fp16-range guard (runtime.h VAE::range_shift): the planning pass reserves the guarded form's arena (a
+                // superset: scaled copies of the skips); the real pass re-runs the decode with more head-room only if a GroupNorm of the
+                // decoder saw non-finite statistics
+                const size_t mk_dec = arena.mark();
+                if (c.dry()) {
+                    c.stats_off = 0;
+                    (void)vae->decode(c, z, use_emasc ? skips : nullptr, vae->range_shift < 0 ? 4 : vae->range_shift);
+                } else {
+                    (void)vae->decode_guarded(st, [&](int sh) {
+                        arena.release(mk_dec);
+                        c.stats_off = 0;
+                        if (stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
+                        Act img = vae->decode(c, z, use_emasc ? skips : nullptr, sh);
+                        c.check(ladi_launch_image_post(img.p, img.ld, B * H * W, images_out, st), "image_post");
+                    });
                     if (latents_out) c.check(ladi_launch_lat_pix_to_nchw(latents, B, hw, latents_out, st), "latents_out");
                     HIP_OK(hipEventRecord(ev[3], st));
                     ev_valid = true;

@@ -85,6 +85,8 @@ void VAE::load(const VAECfg& c, const WeightStore& ws) {
     }
     d_norm_out = load_norm(pool, ws, "decoder.conv_norm_out");
     d_conv_out = load_conv(pool, ws, "decoder.conv_out");
+    d_bad = reinterpret_cast<int*>(pool.alloc(256));
+    if (hipMemset(d_bad, 0, 256) != hipSuccess) throw std::runtime_error("VAE: overflow flag");
 }
 
 VAE::~VAE() { if (stats) (void)hipFree(stats); }
@@ -93,22 +95,28 @@ namespace {
 
 struct VF {
     Ctx& c; VAE& v;
-    // ResnetBlock2D without time embedding; optional extra residual (EMASC skip folded into the producer epilogue)
+    // the residual stream (x in, out of res / attn) is stored multiplied by `s` = 2^-shift (1 except under the decoder's fp16-range guard):
+    //   GroupNorm(s x; eps s^2) == GroupNorm(x; eps) exactly, so everything behind a norm is at its true scale;
+    //   a branch that ENDS in the stream leaves its producer's epilogue multiplied by s (out_scale);
+    //   a convolution that READS the stream directly (shortcut, up-sampler) is linear: its output is already scaled, only its bias needs s.
+    float s = 1.f;
+    float eps_s() const { return v.cfg.eps * s * s; }
+    // ResnetBlock2D without time embedding; optional extra residual (EMASC skip folded into the producer epilogue, pre-scaled by s)
     Act res(const ResBlock& r, const Act& x, const Act* extra) {
         Act out = new_act_with_stats(c, x.n, x.h, x.w, r.cout);
         const size_t mk = c.ar->mark();
-        Act s1 = group_norm(c, r.n1, x, nullptr, v.cfg.groups, v.cfg.eps, 1);
+        Act s1 = group_norm(c, r.n1, x, nullptr, v.cfg.groups, eps_s(), 1);
         ConvOpt o1; o1.stats = true;
         Act h1 = conv2d(c, r.c1, s1, nullptr, o1);
         Act s2 = group_norm(c, r.n2, h1, nullptr, v.cfg.groups, v.cfg.eps, 1);
         Act sc; const Act* resid = &x;
-        if (r.has_sc) { ConvOpt os; sc = conv2d(c, r.sc, x, nullptr, os); resid = &sc; }
+        if (r.has_sc) { ConvOpt os; os.bias_mul = s; sc = conv2d(c, r.sc, x, nullptr, os); resid = &sc; }
         {
             IGemmArgs a; std::memset(&a, 0, sizeof(a));
             a.src0 = s2.p; a.C0 = s2.c; a.ld0 = s2.ld;
             a.Hs = x.h; a.Ws = x.w; a.Ho = x.h; a.Wo = x.w; a.P = (int)x.pixels();
             a.ksize = 3; a.stride = 1; a.pad = 1;
-            a.W = r.c2.w; a.Q = r.c2.cout; a.K = r.c2.K(); a.bias = r.c2.b; a.out_scale = 1.f;
+            a.W = r.c2.w; a.Q = r.c2.cout; a.K = r.c2.K(); a.bias = r.c2.b; a.out_scale = s;
             a.res0 = resid->p; a.ldr0 = resid->ld;
             if (extra) { a.res1 = extra->p; a.ldr1 = extra->ld; }
             launch_conv_into(c, a, out);
@@ -123,7 +131,7 @@ struct VF {
         const bool flash = (C == 128 || C == 256 || C == 512) && (T % 4 == 0);
         Act out = new_act_with_stats(c, x.n, x.h, x.w, C);
         const size_t mk = c.ar->mark();
-        Act g = group_norm(c, at.gn, x, nullptr, v.cfg.groups, v.cfg.eps, 0);
+        Act g = group_norm(c, at.gn, x, nullptr, v.cfg.groups, eps_s(), 0);
         Act tok = g; tok.h = T; tok.w = 1;
         ConvOpt op;
         Act qk = conv2d(c, at.qk, tok, nullptr, op);                 // [n*T][2C]
@@ -165,7 +173,7 @@ struct VF {
             // proj_attn + residual
             std::memset(&a, 0, sizeof(a));
             a.src0 = o.p; a.C0 = C; a.ld0 = C; a.Hs = n * T; a.Ws = 1; a.Ho = n * T; a.Wo = 1; a.P = n * T;
-            a.ksize = 1; a.stride = 1; a.W = at.proj.w; a.Q = C; a.K = at.proj.K(); a.bias = at.proj.b; a.out_scale = 1.f;
+            a.ksize = 1; a.stride = 1; a.W = at.proj.w; a.Q = C; a.K = at.proj.K(); a.bias = at.proj.b; a.out_scale = s;
             a.res0 = x.p; a.ldr0 = x.ld;
             launch_conv_into(c, a, out);
         }
@@ -200,12 +208,24 @@ Act VAE::encode(Ctx& c, const Act& x, Act feats[5]) {
     return conv2d(c, e_conv_out, g, nullptr, oc);  // moments (quant_conv folded)
 }
 
-Act VAE::decode(Ctx& c, const Act& z, const Act* skips) {
+Act VAE::decode(Ctx& c, const Act& z, const Act* skips, int shift) {
     VF f{c, *this};
+    f.s = std::ldexp(1.f, -shift);
+    c.bad = d_bad;
     const int L = cfg.layers_per_block;
-    // slot i = EMASC output for encoder feature idx i+1; a slot without a tensor is an int_layers selection that omits it (vae.py:190-205)
-    auto sk = [&](int i) -> const Act* { return (skips && skips[i].p) ? &skips[i] : nullptr; };
-    ConvOpt o; o.stats = true;
+    // slot i = EMASC output for encoder feature idx i+1; a slot without a tensor is an int_layers selection that omits it (vae.py:190-205).
+    // Skips that are added INTO the stream (slots 1..4) must carry the stream's scale: scaled copies under the range guard
+    Act scaled[5];
+    for (int i = 1; i < 5; ++i) {
+        if (!(skips && skips[i].p) || shift == 0) continue;
+        scaled[i] = c.new_act(skips[i].n, skips[i].h, skips[i].w, skips[i].c);
+        if (!c.dry()) c.check(ladi_launch_scale_h16(skips[i].p, skips[i].ld, scaled[i].p, scaled[i].ld, skips[i].pixels(), skips[i].c, f.s, c.st), "skip scale");
+    }
+    auto sk = [&](int i) -> const Act* {
+        if (!(skips && skips[i].p)) return nullptr;
+        return (shift != 0 && i > 0) ? &scaled[i] : &skips[i];
+    };
+    ConvOpt o; o.stats = true; o.out_scale = f.s;
     Act h = conv2d(c, d_conv_in, z, nullptr, o);
     h = f.res(d_mid[0], h, nullptr);
     h = f.attn(d_attn, h);
@@ -215,15 +235,25 @@ Act VAE::decode(Ctx& c, const Act& z, const Act* skips) {
     for (int i = 0; i < 4; ++i) {
         for (int j = 0; j < L + 1; ++j) h = f.res(d_res[ri++], h, nullptr);
         if (i < 3) {
-            ConvOpt ou; ou.ups = 1; ou.stats = true;
+            ConvOpt ou; ou.ups = 1; ou.stats = true; ou.bias_mul = f.s;     // reads the scaled stream: linear, only the bias needs s
             ou.res0 = sk(3 - i);
             h = conv2d(c, d_up[i], h, nullptr, ou);
         }
     }
-    // vae.py:200-205: conv_norm_out -> SiLU -> (+ feats for int layer 1) -> conv_out
-    Act g = group_norm(c, d_norm_out, h, nullptr, cfg.groups, cfg.eps, 1, sk(0));
+    // vae.py:200-205: conv_norm_out -> SiLU -> (+ feats for int layer 1, true scale: it is added behind the norm) -> conv_out
+    Act g = group_norm(c, d_norm_out, h, nullptr, cfg.groups, f.eps_s(), 1, sk(0));
     ConvOpt oc; oc.out_ld = 4;
+    c.bad = nullptr;
     return conv2d(c, d_conv_out, g, nullptr, oc);
+}
+
+bool VAE::overflowed(hipStream_t st) {
+    if (!d_bad) return false;
+    int h = 0;
+    if (hipMemcpyAsync(&h, d_bad, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        throw std::runtime_error("VAE: reading the overflow flag failed");
+    if (h) (void)hipMemsetAsync(d_bad, 0, sizeof(int), st);
+    return h != 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -205,6 +205,24 @@ class NativeVAE(_Base):
             self.lib.ladi_vae_destroy(self.h)
             self.h = None
 
+    @property
+    def range_shift(self):
+        """fp16-range guard of the decoder: "auto" (default) decodes with the residual stream at its true scale and, when a GroupNorm
+        reports non-finite statistics (an fp16 overflow upstream), again with the stream stored x 2^-4, then 2^-8; an int k fixes the stream
+        scale at 2^-k.  The reference decodes in whatever dtype the caller chose (src/models/AutoencoderKL.py:159-188); SD VAE checkpoints
+        are known to leave the fp16 range there.  `last_range_shift` tells what the last decode used."""
+        return getattr(self, "_range_shift", "auto")
+
+    @range_shift.setter
+    def range_shift(self, k):
+        kk = -1 if k in ("auto", None) else int(k)
+        check(self.lib.ladi_vae_set_range_shift(self.h, kk), "ladi_vae_set_range_shift")
+        self._range_shift = "auto" if kk < 0 else kk
+
+    @property
+    def last_range_shift(self):
+        return self.lib.ladi_vae_last_range_shift(self.h)
+
     def encode(self, x, return_dict=True):
         x = x.contiguous()
         B, _, H, W = x.shape
