@@ -71,7 +71,7 @@ def parse():
     p.add_argument("--width", type=int, default=None)
     p.add_argument("--size", default="full", choices=["full", "tiny"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-runs", type=int, default=1, help="end-to-end runs of config #0 on the host cores (median reported; BASELINE.md §3 protocol: 3)")
+    p.add_argument("--cpu-runs", type=int, default=3, help="end-to-end runs of config #0 on the host cores, median reported (BASELINE.md §3 protocol: 3)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--measure-traffic", action="store_true",
@@ -81,6 +81,7 @@ def parse():
                    help="only the dominant-kernel measurement: CFG UNet forwards at the bench batch (the command the rocprofv3 "
                         "summaries under profiles/ are taken from)")
     p.add_argument("--roofline-iters", type=int, default=4)
+    p.add_argument("--no-tail", action="store_true", help="skip the D2H + PIL leg (with_d2h_pil_images_per_s)")
     return p.parse_args()
 
 
@@ -249,6 +250,35 @@ def cpu_baseline(sds, cfgs, runs, target_evals, scheduler, size="full"):
             "config0_seconds_per_image": round(t_run, 2), "config0_images_per_s": round(1.0 / t_run, 5)}
 
 
+def make_step(run_local, local, lo, per_rank, global_B):
+    """The step of the bench as a function (also driven, with a stub run_local, by the 2-process gloo rehearsal in tests/test_cpu.py): the
+    row materialiser hands run_sharded this rank's resident rows of the GLOBAL batch [lo, lo + per_rank), run_sharded runs the local
+    shard and performs the path's only collective (all-gather of the uint8 images; RCCL on the GPU box)."""
+    from ladi_vton_amd.parallel import run_sharded
+
+    def rows(lo_, hi_):
+        assert (lo_, hi_) == (lo, lo + per_rank), ((lo_, hi_), (lo, lo + per_rank))
+        return local
+
+    def one_step():
+        return run_sharded(run_local, rows, batch=global_B)
+    return one_step
+
+
+def d2h_pil_tail(images_u8):
+    """what the reference does with the result (tryon_pipe.py:357-360 numpy_to_pil, inference.py:314-324 save as JPEG quality 95): device ->
+    host copy, PIL image per sample, encode.  Encoded into memory (no disk in the measurement)."""
+    import io
+    from PIL import Image
+    host = images_u8.cpu().numpy()
+    n = 0
+    for im in host:
+        buf = io.BytesIO()
+        Image.fromarray(im).save(buf, format="JPEG", quality=95)
+        n += buf.tell()
+    return n
+
+
 def main():
     a = parse()
     cfg = CONFIGS[a.config]
@@ -313,12 +343,7 @@ def main():
                                inp["noise_cloth"], inp["noise_latents"], inp["noise_masked"], H, W, steps_inf, 7.5, 1.0, False, not a.no_graph,
                                return_device=True)
 
-    def rows(lo_, hi_):   # row materialiser of the global batch for run_sharded: this rank's rows are already resident
-        assert (lo_, hi_) == (lo, lo + B)
-        return local
-
-    def one_step():
-        return run_sharded(run_local, rows, batch=global_B)   # contiguous row shards + the path's only collective (RCCL all-gather of uint8 images)
+    one_step = make_step(run_local, local, lo, B, global_B)   # contiguous row shards + the path's only collective (RCCL all-gather of uint8 images)
 
     def fence():
         torch.cuda.synchronize()
@@ -347,6 +372,23 @@ def main():
     dt = float(tt.item())
     assert out.shape[0] == global_B and out.dtype == torch.uint8
     images_per_s = global_B * a.steps / dt if a.steps else 0.0
+    # the same step WITH the reference's output tail (D2H + PIL + JPEG encode of every image, on rank 0's host cores),
+    # timed separately so that `value` stays the device-resident number
+    tail = None
+    if a.steps and not a.no_tail and not a.roofline_only:
+        nt = min(a.steps, 3)
+        fence()
+        t1 = time.time()
+        nbytes = 0
+        for _ in range(nt):
+            out = one_step()
+            if rank == 0:
+                nbytes = d2h_pil_tail(out)
+        fence()
+        dt_tail = max(time.time() - t1, 1e-9)
+        tail = {"images_per_s": round(global_B * nt / dt_tail, 4), "ms_per_step": round(dt_tail / nt * 1000.0, 2), "steps": nt,
+                "what": "step + D2H of the uint8 batch + PIL.Image + JPEG(quality 95) encode of every image on rank 0 (inference.py:314-324)",
+                "jpeg_bytes_per_batch": nbytes}
     evals = steps_inf + (1 if scheduler == "pndm" else 0)
     lib = _lib.load()
     stage = (ctypes.c_float * 3)()
@@ -412,6 +454,7 @@ def main():
                        "parallelism": "dp%d (contiguous row shards of the global batch + RCCL all-gather of uint8 images)" % world,
                        "hipgraph": not a.no_graph},
             "stage_ms_rank0": stage_ms, "model_build_s": round(t_build, 1),
+            "with_d2h_pil_images_per_s": tail["images_per_s"] if tail else None, "d2h_pil_tail": tail,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

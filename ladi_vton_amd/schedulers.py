@@ -68,10 +68,22 @@ class DDIMScheduler(_SchedulerBase):
         var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
         std = float(eta) * max(var, 0.0) ** 0.5
         prev = a_p ** 0.5 * x0 + max(1 - a_p - std * std, 0.0) ** 0.5 * e
+        if use_clipped_model_output:
+            raise NotImplementedError("use_clipped_model_output=True is not implemented (the try-on pipeline never sets it: tryon_pipe.py:740)")
         if eta > 0:
             if variance_noise is None:
-                gdev = generator.device if generator is not None else sample.device
-                variance_noise = torch.randn(sample.shape, generator=generator, device=gdev, dtype=sample.dtype).to(sample.device)
+                # diffusers 0.14 randn_tensor(model_output.shape, generator, device, dtype=model_output.dtype): drawn on the generator's
+                # device; a LIST of generators draws one [1, ...] tensor per sample from that sample's generator
+                shape, dt = tuple(model_output.shape), model_output.dtype
+                if isinstance(generator, (list, tuple)):
+                    if len(generator) != shape[0]:
+                        raise ValueError("You have passed a list of generators of length %d, but requested an effective batch size of %d."
+                                         % (len(generator), shape[0]))
+                    variance_noise = torch.cat([torch.randn((1,) + shape[1:], generator=g_, device=g_.device, dtype=dt).to(sample.device)
+                                                for g_ in generator], dim=0)
+                else:
+                    gdev = generator.device if generator is not None else sample.device
+                    variance_noise = torch.randn(shape, generator=generator, device=gdev, dtype=dt).to(sample.device)
             prev = prev + std * variance_noise.float()
         return SimpleNamespace(prev_sample=prev.to(sample.dtype))
 

@@ -512,6 +512,53 @@ def test_sharded_run_world_size_2_gloo(tmp_path):
         assert p.returncode == 0 and ("OK %d" % r) in o, o
 
 
+_BENCH_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import bench
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg = bench.CONFIGS[3]                                   # BASELINE configs[3]: 32 pairs per GPU (weak scaling), producers in the step
+B, H, W = cfg["batch"], 32, 24                           # real per-GPU batch, small images: this rehearses the WIRING, not the kernels
+assert B == 32 and cfg["producers"]
+global_B, lo = B * world, rank * B
+local = bench.make_rows(lo, lo + B, H, W, 77, 16, "cpu")
+def run_local(inp):                                      # stand-in for producers + fused try-on: a per-row function of the row's tensors
+    assert inp["image"].shape[0] == B and inp["word_ids"].shape == (B, 77) and inp["prompt_embeds"].shape[0] == B
+    x = inp["image"] * 0.25 + inp["cloth"] * 0.25 + 0.5 + inp["noise_latents"].mean(dim=(1, 2, 3)).view(-1, 1, 1, 1) * 0.01
+    return x.permute(0, 2, 3, 1).clamp(0, 1).float().contiguous()
+step = bench.make_step(run_local, local, lo, B, global_B)
+out = step()
+assert out.shape == (global_B, H, W, 3) and out.dtype == torch.uint8
+# every rank must hold the whole batch, row g a function of g only: rebuild ALL rows here and compare
+allrows = bench.make_rows(0, global_B, H, W, 77, 16, "cpu")
+parts = []
+for r in range(world):
+    blk = {k: (v[r * B:(r + 1) * B] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == global_B else v) for k, v in allrows.items()}
+    parts.append((run_local(blk) * 255.0).round().clamp(0, 255).to(torch.uint8))
+assert torch.equal(out, torch.cat(parts)), rank
+n = bench.d2h_pil_tail(out[:2])                          # the output tail of the bench line runs on this host too
+assert n > 0
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_bench_step_wiring_config3_world_size_2_gloo(tmp_path):
+    """rehearsal of `bench.py --config 3 --gpus N` without a node: bench.make_rows (per-global-row generators),
+    bench.make_step (row materialiser -> run_sharded -> all-gather of uint8 images) at the real per-GPU batch of 32 with a stub in
+    place of the native pipeline, 2 gloo processes: every rank ends up with the same 64-image batch, row g depending on g only"""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(_BENCH_WORKER % {"root": ROOT})
+    port = str(29000 + (os.getpid() % 400))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("OK %d" % r) in o, o
+
+
 def test_dataset_preprocessing_matches_real_reference_classes(tmp_path):
     """ladi_vton_amd.dataset (host-side VITON-HD / DressCode readers: label-map algebra, PIL rasterisation, box dilation, pose heat-maps)
     vs fixtures produced by the REAL src/dataset/vitonhd.py / dresscode.py classes on the same synthetic trees (oracle/make_golden.py:
