@@ -111,7 +111,7 @@ struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; in
 // tile configurations (0 = choose: measured per shape when autotuning is on, else the cost model below).
 // {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K,
 //  K step, offered to the tuner}
-constexpr int NCFG = 73;
+constexpr int NCFG = 87;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1, 0, false},
     {128, 256, 2, true, 0.80f, 4, 1, 1, 32, true},   // 1: <2,2,2,4> BK32 NST3
@@ -196,8 +196,25 @@ const CfgInfo kCfg[NCFG + 1] = {
     {256, 128, 1, false, 0.00f, 2, 64, 4, 64, true},  // 71: cfg 64 + split-K 4
     {128, 64, 1, false, 0.00f, 1, 66, 4, 64, true},   // 72: cfg 66 + split-K 4
     {128, 128, 1, false, 0.00f, 2, 62, 4, 64, true},  // 73: cfg 62 + split-K 4
+    // 74..83 (round 3): halo-resident 3x3 convolution (igemm_halo.hip): the pixel range of all nine taps staged ONCE per channel chunk,
+    // only the weight tile streamed per tap; 8 waves, one workgroup per CU
+    {128, 256, 1, false, 0.00f, 2, 74, 1, 64, true},  // 74: 128x256, double halo buffer
+    {256, 256, 1, false, 0.00f, 2, 75, 1, 64, true},  // 75: 256x256, single halo buffer
+    {320, 256, 1, false, 0.00f, 2, 76, 1, 64, true},  // 76: 320x256, single halo buffer
+    {128, 128, 1, false, 0.00f, 1, 77, 1, 64, true},  // 77: 128x128
+    {256, 128, 1, false, 0.00f, 1, 78, 1, 64, true},  // 78: 256x128
+    {128, 256, 1, false, 0.00f, 2, 74, 2, 64, true},  // 79: cfg 74 + split-K 2
+    {128, 128, 1, false, 0.00f, 1, 77, 2, 64, true},  // 80: cfg 77 + split-K 2
+    {256, 128, 1, false, 0.00f, 1, 78, 2, 64, true},  // 81: cfg 78 + split-K 2
+    {256, 256, 1, false, 0.00f, 2, 75, 2, 64, true},  // 82: cfg 75 + split-K 2
+    {128, 128, 1, false, 0.00f, 1, 77, 4, 64, true},  // 83: cfg 77 + split-K 4
+    {128, 128, 2, false, 0.00f, 2, 84, 1, 64, true},  // 84: halo 128x128, 4 waves, two workgroups per CU
+    {128, 192, 2, false, 0.00f, 3, 85, 1, 64, true},  // 85: halo 128x192, 4 waves, two workgroups per CU
+    {128, 128, 2, false, 0.00f, 2, 84, 2, 64, true},  // 86: cfg 84 + split-K 2
+    {128, 128, 2, false, 0.00f, 2, 84, 4, 64, true},  // 87: cfg 84 + split-K 4
 };
 inline bool is_lc(int base) { return base >= 62 && base <= 68; }
+inline bool is_halo(int base) { return (base >= 74 && base <= 78) || base == 84 || base == 85; }
 
 // rocprofv3's name of the kernel a configuration launches (bench.py groups its per-launch timings by symbol)
 std::string cfg_symbol(int c) {
@@ -211,6 +228,13 @@ std::string cfg_symbol(int c) {
         case 56: return "igemm8_kernel<2, 1, 0>";
         case 57: return "igemm8_kernel<5, 1, 0>";
         case 58: return "igemm8_kernel<3, 2, 0>";
+        case 74: return "igemm_halo_kernel<2, 2, 2, 3, 4>";
+        case 75: return "igemm_halo_kernel<4, 2, 1, 3, 4>";
+        case 76: return "igemm_halo_kernel<5, 2, 1, 2, 4>";
+        case 77: return "igemm_halo_kernel<2, 1, 2, 4, 4>";
+        case 78: return "igemm_halo_kernel<4, 1, 1, 3, 4>";
+        case 84: return "igemm_halo_kernel<2, 2, 1, 2, 2>";
+        case 85: return "igemm_halo_kernel<2, 3, 1, 2, 2>";
         case 62: return "igemm_lc_kernel<2, 2, 2, 2, 2, 4>";
         case 63: return "igemm_lc_kernel<2, 2, 2, 2, 2, 5>";
         case 64: return "igemm_lc_kernel<2, 2, 4, 2, 2, 3>";
@@ -239,6 +263,13 @@ int launch_base(int cfg, const IGemmArgs& a, int batch, hipStream_t st) {
         case 56: return ladi_launch_igemm8(a, 2, 1, batch, st);
         case 57: return ladi_launch_igemm8(a, 5, 1, batch, st);
         case 58: return ladi_launch_igemm8(a, 3, 2, batch, st);
+        case 74: return ladi_launch_igemm_halo(a, 2, 2, 2, batch, st);
+        case 75: return ladi_launch_igemm_halo(a, 4, 2, 1, batch, st);
+        case 76: return ladi_launch_igemm_halo(a, 5, 2, 1, batch, st);
+        case 77: return ladi_launch_igemm_halo(a, 2, 1, 2, batch, st);
+        case 78: return ladi_launch_igemm_halo(a, 4, 1, 1, batch, st);
+        case 84: return ladi_launch_igemm_halo(a, 2, 2, 10, batch, st);
+        case 85: return ladi_launch_igemm_halo(a, 2, 3, 10, batch, st);
         case 62: return ladi_launch_igemm_lc(a, 2, 2, 4, batch, st);
         case 63: return ladi_launch_igemm_lc(a, 2, 2, 5, batch, st);
         case 64: return ladi_launch_igemm_lc(a, 4, 2, 3, batch, st);
@@ -339,6 +370,7 @@ static bool cfg_admissible(const IGemmArgs& a, int batch, int c, bool strict) {
     }
     if (a.ln_gamma && !a.ln_scratch) return false;                    // no scratch: only the fused (X-stationary) form
     if (is_lc(ci.base) && (a.ups || batch != 1)) return false;        // loader / consumer kernel: no folded upsample, no batched launches
+    if (is_halo(ci.base) && !ladi_igemm_halo_eligible(a, batch)) return false;   // halo-resident kernel: 3x3 stride-1 convolutions on narrow images
     if (geglu && !ci.geglu_ok) return false;
     if (ci.bk == 64 && ((a.C0 % 64) || (a.C1 % 64))) return false;
     if (ci.split > 1 && (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel)) return false;

@@ -1,0 +1,294 @@
+// Halo-resident 3x3 convolution (round 3), reached through ladi_launch_igemm (cfg 74..).
+//
+// Why.  What bounds every implicit-GEMM tile below 256x256 on this chip is the global -> LDS staging rate (25-32 B/clk/CU in these
+// kernels; tools/dma_conv_pattern.hip), and the ring kernels stage the PIXEL operand once per filter tap: nine
+// shifted copies of the same activation rows per channel chunk.  In row-major pixel order a tap is a LINEAR shift: output pixel p reads
+// input pixel p + (dy-1)*W + (dx-1).  So for a tile of BP consecutive output pixels the nine taps live in ONE contiguous range of
+// BP + 2W + 2 input pixels.  This kernel stages that range once per 64-channel chunk (the "halo tile"), keeps it in LDS for all nine taps
+// and streams only the WEIGHT tile per tap; the tap is applied when the B fragments are READ (row = pixel + tap shift), and the lanes
+// whose tap falls outside the image (left / right edge wrap-around, top / bottom rows, the neighbouring sample) read a row of zeros
+// instead.  Staged bytes per channel chunk drop from 9 (BQ + BP) x 128 B to (9 BQ + BP + 2W + 2) x 128 B -- 0.42x for a 128x256 tile at
+// W = 24 -- which moves the 32x24 / 64x48-level convolutions from staging-bound to MFMA-bound.
+//
+// Scope: 3x3, stride 1, pad 1, no folded upsample, W <= 48 (every level of the UNet at 512x384; wider images would need a 2-D blocked halo
+// tile), channel counts multiples of 64, two-source concat supported (the chunk selects the source).  8 waves (2 x 4) per workgroup, one
+// workgroup per CU, weights double-buffered; the halo tile double-buffered (NXB = 2: the next chunk's tile arrives spread over the taps)
+// or single (NXB = 1, for the 320-row weight tile: one exposed tile load per nine taps).  Same fragment layout, swizzle, epilogue and
+// split-K convention as igemm_kernel.h.
+#include "common.h"
+#include "kernels.h"
+#include "igemm_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int HALO_WMAX = 48;
+
+// halo-tile passes issued at tap `tt` of a chunk that has a successor (the LX passes of the next chunk's tile are spread over taps 0..7)
+template <int LX>
+constexpr int nx_at(int tt) { return tt < 8 ? (LX * (tt + 1)) / 8 - (LX * tt) / 8 : 0; }
+// pieces of halo tile issued in the D steps before tap t (taps < 0 belong to the previous chunk, which always has a successor; the
+// current chunk's own taps count only if it has one: `pf`)
+template <int LX, int NXB>
+constexpr int nx_sum(int t, int D, bool pf) {
+    if (NXB != 2) return 0;
+    int n = 0;
+    for (int k = 1; k <= D; ++k) {
+        const int tt = t - k;
+        if (tt >= 0) n += pf ? nx_at<LX>(tt) : 0;
+        else n += nx_at<LX>(9 + tt);
+    }
+    return n;
+}
+
+template <int TQ, int TP, int NXB, int NSTW, int WPN>
+__global__ __launch_bounds__(128 * WPN, 2) void igemm_halo_kernel(const IGemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // device pass only (see igemm_kernel.h)
+    constexpr int WQ = 2, WP = WPN, BK = 64, NT = 128 * WPN;    // 8 waves (2 x 4), or 4 waves (2 x 2) with two workgroups per CU
+    constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
+    constexpr int RPP = NT / 8;                                  // 64 tile rows per DMA pass of the workgroup
+    constexpr int RQ = (BQ + RPP - 1) / RPP;                     // weight passes per tap
+    constexpr int XROWS = (BP + 2 * HALO_WMAX + 2 + RPP - 1) / RPP * RPP;   // rows of one halo-tile buffer (whole passes)
+    constexpr int LX = XROWS / RPP;                              // halo passes per channel chunk
+    constexpr int WSLOT = RQ * RPP * BK;                         // halves per weight slot (padded to whole passes)
+    constexpr int XBUF = XROWS * BK;                             // halves per halo buffer
+    constexpr int D = NSTW - 1;                                  // weight tiles issued ahead of the one being multiplied
+    static_assert(NSTW >= 2 && NSTW <= 4, "weight ring depth");
+    constexpr int ZOFF = NSTW * WSLOT + NXB * XBUF;              // the row of zeros (halves)
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    h16* smem = reinterpret_cast<h16*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
+    int qt, pt;
+    {
+        const int b = blockIdx.x;
+        if (a.tile_map == 1) {
+            const int npx = (np + 7) >> 3, xcd = b & 7, loc = b >> 3;
+            pt = xcd * npx + loc / nq; qt = loc % nq;
+            if (pt >= np) return;
+        } else if (a.tile_map == 2) {
+            const int nqx = (nq + 7) >> 3, xcd = b & 7, loc = b >> 3;
+            qt = xcd * nqx + loc / np; pt = loc % np;
+            if (qt >= nq) return;
+        } else { qt = b % nq; pt = b / nq; }
+    }
+    const int q0 = qt * BQ, p0 = pt * BP;
+    const int z = blockIdx.z;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wq = wave / WP, wp = wave % WP;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int r0 = tid >> 3;                                     // row inside a DMA pass (RPP rows)
+    const int c8 = tid & 7;
+
+    const int Ws = a.Ws, Hs = a.Hs, HW = Hs * Ws;
+    const int Ct = a.C0 + a.C1;
+    const int ldw = a.ldw ? a.ldw : a.K;
+    // descriptors with the exact extent of each operand: rows before the first / after the last pixel of the tensor are zero-filled
+    // (the launcher guarantees P * ld * 2 < 2^31)
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.src0), 0, (unsigned)((size_t)a.P * a.ld0 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.src1 ? a.src1 : a.src0), 0,
+                                                                         (unsigned)((size_t)a.P * (a.src1 ? a.ld1 : a.ld0) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.W), 0, 0x7FFFFFFF, 0x00020000);
+
+    // ---- DMA-side per-lane offsets (constant over the K loop)
+    unsigned wbase[RQ];
+#pragma unroll
+    for (int i = 0; i < RQ; ++i) {
+        const int row = r0 + RPP * i, q = q0 + row;
+        const int clog = c8 ^ ((row >> 1) & 7);
+        wbase[i] = (row < BQ && q < a.Q) ? (unsigned)(((size_t)q * ldw + clog * 8) * 2) : OOB;
+    }
+    unsigned xo0[LX], xo1[LX];
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+        const int row = r0 + RPP * i;                            // halo-tile row = input pixel p0 - Ws - 1 + row
+        const long long pin = (long long)p0 - Ws - 1 + row;
+        const int clog = c8 ^ ((row >> 1) & 7);
+        const bool ok = pin >= 0 && pin < a.P;
+        xo0[i] = ok ? (unsigned)((pin * a.ld0 + clog * 8) * 2) : OOB;
+        xo1[i] = ok ? (unsigned)((pin * a.ld1 + clog * 8) * 2) : OOB;
+    }
+    // ---- consumer-side: this lane's pixel in each of its TP blocks: halo-tile row of the centre tap and the 9-bit validity mask
+    int rb[TP]; unsigned vm[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int pl = (wp * TP + j) * 32 + l31, p = p0 + pl;
+        rb[j] = pl + Ws + 1;
+        unsigned m = 0;
+        if (p < a.P) {
+            const int rem = p % HW, oy = rem / Ws, ox = rem - oy * Ws;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if ((unsigned)(oy + t / 3 - 1) < (unsigned)Hs && (unsigned)(ox + t % 3 - 1) < (unsigned)Ws) m |= 1u << t;
+        }
+        vm[j] = m;
+    }
+
+    // split-K over whole (chunk, tap) steps
+    int nk = a.K / BK, s_begin = 0;
+    if (a.splitk > 1) {
+        const int sps = (nk + a.splitk - 1) / a.splitk;
+        s_begin = z * sps;
+        nk = max(0, min(sps, nk - s_begin));
+    }
+    const int s_end = s_begin + nk;
+
+    auto issue_w = [&](int s) {        // weight tile of step s = (chunk s / 9, tap s % 9) into ring slot s % NSTW
+        const int cb = (s / 9) * BK, tap = s - (s / 9) * 9;
+        const unsigned so = (unsigned)((tap * Ct + cb) * 2);
+        char* base = smem_raw + (size_t)(s % NSTW) * (WSLOT * 2) + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < RQ; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(base + i * (RPP * BK * 2)), 16, wbase[i], so, 0, 0);
+    };
+    auto issue_x = [&](int chunk, int i0, int i1) {   // passes [i0, i1) of the halo tile of `chunk` into buffer chunk % NXB
+        const int cb = chunk * BK;
+        const bool s0 = cb < a.C0;
+        const __amdgpu_buffer_rsrc_t rs = s0 ? rs0 : rs1;
+        const unsigned so = (unsigned)((s0 ? cb : cb - a.C0) * 2);
+        char* base = smem_raw + (size_t)(NSTW * WSLOT + (NXB == 2 ? (chunk & 1) : 0) * XBUF) * 2 + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < LX; ++i)
+            if (i >= i0 && i < i1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(base + i * (RPP * BK * 2)), 16, s0 ? xo0[i] : xo1[i], so, 0, 0);
+    };
+
+    f32x16 acc[TQ][TP];
+#pragma unroll
+    for (int i = 0; i < TQ; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (tid < 8) *reinterpret_cast<h16x8*>(smem + ZOFF + tid * 8) = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    const int c_first = s_begin / 9, c_last = (s_end - 1) / 9;
+    if (nk > 0) {
+        issue_x(c_first, 0, LX);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (s_begin + d < s_end) issue_w(s_begin + d);
+    }
+
+    for (int c = c_first; c <= c_last && nk > 0; ++c) {
+        const h16* sX = smem + NSTW * WSLOT + (NXB == 2 ? (c & 1) : 0) * XBUF;
+        const bool prefetch_x = (NXB == 2) && (c < c_last);
+        static_for<0, 9>([&](auto Tc) {
+            constexpr int t = decltype(Tc)::value;
+            const int s = c * 9 + t;
+            if (s >= s_begin && s < s_end) {
+                // Counted wait for the weight tile of THIS step.  DMAs complete in issue order per wave; behind W(s) (issued D steps ago) the
+                // wave has issued, per step since then, the pieces of the next chunk's halo tile (nx(tap) of them while the chunk has a
+                // successor) and one weight tile (RQ pieces).  Steady state only -- near the ends of the slice the count is smaller than
+                // the formula, and a count that is too LARGE would not wait long enough: there the wait is vmcnt(0).
+                constexpr int NPF = RQ * (D - 1) + nx_sum<LX, NXB>(t, D, true), NNOPF = RQ * (D - 1) + nx_sum<LX, NXB>(t, D, false);
+                static_assert(NPF <= 63, "vmcnt is a 6-bit counter");
+                // (single halo buffer: the tile of this chunk was issued BEHIND the weight tiles at the end of the previous chunk, so the first
+                // tap drains everything)
+                const bool steady = (s - D >= s_begin) && (s + D - 1 < s_end) && !(NXB == 1 && t == 0);
+                if (steady && prefetch_x) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPF) : "memory");
+                else if (steady) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NNOPF) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (s + D < s_end) issue_w(s + D);
+                if constexpr (NXB == 2 && t < 8) {
+                    // a split-K slice may enter the chunk at tap t > 0: its first step also issues the passes of the taps it skipped
+                    // (those steps are not "steady": they wait with vmcnt(0))
+                    if (prefetch_x) issue_x(c + 1, s == s_begin ? 0 : (LX * t) / 8, (LX * (t + 1)) / 8);
+                }
+                const h16* sW = smem + (s % NSTW) * WSLOT;
+                const int tshift = (t / 3 - 1) * Ws + (t % 3 - 1);
+                int xoff[TP];          // half offset of the lane's row in the halo tile (or the zero row), swizzle term separate
+                int xsw[TP];
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    const bool valid = (vm[j] >> t) & 1u;
+                    const int row = rb[j] + tshift;
+                    xoff[j] = valid ? (int)(sX - smem) + row * 64 : ZOFF;
+                    xsw[j] = valid ? ((row >> 1) & 7) : 0;
+                }
+                // fragments double-buffered in registers when the accumulators leave room (the 320x256 tile holds 160 accumulator registers:
+                // single buffer there, its partner wave on the SIMD covers the LDS latency)
+                constexpr int DB = (TQ * TP * 16 + 2 * (TQ + TP) * 4 <= 200) ? 1 : 0;
+                h16x8 af[1 + DB][TQ], bf[1 + DB][TP];
+                auto load_frags = [&](auto Kc) {
+                    constexpr int kk = decltype(Kc)::value;
+                    const int chunk = kk * 2 + hh;
+#pragma unroll
+                    for (int i = 0; i < TQ; ++i) af[kk & DB][i] = *reinterpret_cast<const h16x8*>(sW + swz<BK>((wq * TQ + i) * 32 + l31, chunk));
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) bf[kk & DB][j] = *reinterpret_cast<const h16x8*>(smem + xoff[j] + ((chunk ^ xsw[j]) << 3));
+                };
+                if constexpr (DB) load_frags(IntC<0>{});
+                static_for<0, 4>([&](auto Kc) {
+                    constexpr int kk = decltype(Kc)::value;
+                    if constexpr (DB) { if constexpr (kk + 1 < 4) load_frags(IntC<kk + 1>{}); }
+                    else load_frags(IntC<kk>{});
+#pragma unroll
+                    for (int i = 0; i < TQ; ++i)
+#pragma unroll
+                        for (int j = 0; j < TP; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & DB][i], bf[kk & DB][j], acc[i][j], 0, 0, 0);
+                });
+            }
+        });
+        if constexpr (NXB == 1) {
+            if (c < c_last) {        // single halo buffer: every wave must be done with it before the next chunk's tile overwrites it
+                asm volatile("s_barrier" ::: "memory");
+                issue_x(c + 1, 0, LX);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    igemm_epilogue<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane);
+#endif
+}
+
+template <int TQ, int TP, int NXB, int NSTW, int WPN>
+int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
+    constexpr int BQ = 64 * TQ, BP = 32 * WPN * TP, RPP = 16 * WPN;
+    constexpr int RQ = (BQ + RPP - 1) / RPP, XROWS = (BP + 2 * HALO_WMAX + 2 + RPP - 1) / RPP * RPP;
+    constexpr int SMEM = (NSTW * RQ * RPP * 64 + NXB * XROWS * 64) * (int)sizeof(h16) + 128;
+    static_assert(SMEM <= 160 * 1024, "LDS budget of one CU");
+    static_assert(SMEM >= igemm_epilogue_lds_bytes<2, WPN, TQ>(), "epilogue patches must fit");
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups || a.Ws > HALO_WMAX || a.Ho != a.Hs || a.Wo != a.Ws) return -16;
+    if ((a.C0 % 64) || (a.C1 % 64) || (batch != 1 && a.splitk <= 1)) return -16;
+    if ((size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 >= 0x7FFFFFFFull) return -16;   // 32-bit byte offsets from the tensor base
+    static bool attr_set = false;
+    auto kfn = igemm_halo_kernel<TQ, TP, NXB, NSTW, WPN>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return -10;
+        attr_set = true;
+    }
+    const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
+    int blocks = nq * np;
+    a.tile_map = 0;
+    if (np >= 16) { a.tile_map = 1; blocks = 8 * ((np + 7) / 8) * nq; }
+    else if (nq >= 16) { a.tile_map = 2; blocks = 8 * ((nq + 7) / 8) * np; }
+    dim3 grid((unsigned)blocks, 1, (unsigned)batch);
+    hipLaunchKernelGGL(kfn, grid, dim3(128 * WPN), SMEM, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+}  // namespace
+
+bool ladi_igemm_halo_eligible(const IGemmArgs& a, int batch) {
+    return a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Ws <= HALO_WMAX && a.Ho == a.Hs && a.Wo == a.Ws && !(a.C0 % 64) && !(a.C1 % 64) &&
+           batch == 1 && (size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 < 0x7FFFFFFFull;
+}
+
+// (tq, tp): wave tile in 32-blocks on the 2 x 4 wave grid -> workgroup tile (64 tq) x (128 tp); nxb: halo buffers (10: the 4-wave form,
+// 2 x 2 waves -> (64 tq) x (64 tp), one halo buffer)
+int ladi_launch_igemm_halo(const IGemmArgs& a, int tq, int tp, int nxb, int batch, hipStream_t st) {
+    if (tq == 2 && tp == 2 && nxb == 2) return launch_halo<2, 2, 2, 3, 4>(a, batch, st);   // 128x256, 3 weight slots (144 KB)
+    if (tq == 4 && tp == 2 && nxb == 1) return launch_halo<4, 2, 1, 3, 4>(a, batch, st);   // 256x256, single halo buffer, 3 weight slots (144 KB)
+    if (tq == 5 && tp == 2 && nxb == 1) return launch_halo<5, 2, 1, 2, 4>(a, batch, st);   // 320x256, single halo buffer, 2 weight slots (128 KB)
+    if (tq == 2 && tp == 1 && nxb == 2) return launch_halo<2, 1, 2, 4, 4>(a, batch, st);   // 128x128, 4 weight slots (128 KB)
+    if (tq == 4 && tp == 1 && nxb == 1) return launch_halo<4, 1, 1, 3, 4>(a, batch, st);   // 256x128, single halo buffer, 3 weight slots (128 KB)
+    // 4-wave workgroups, TWO per CU (64-72 KB each): their barriers are independent, so one workgroup multiplies while the other waits
+    if (tq == 2 && tp == 2 && nxb == 10) return launch_halo<2, 2, 1, 2, 2>(a, batch, st);  // 128x128
+    if (tq == 2 && tp == 3 && nxb == 10) return launch_halo<2, 3, 1, 2, 2>(a, batch, st);  // 128x192
+    return -7;
+}

@@ -22,6 +22,10 @@ int ladi_launch_igemm8(const IGemmArgs& a, int tq, int tp, int batch, hipStream_
 // ---- igemm_lc.hip: loader / consumer kernel, consumer wave tile (tq*32 channels) x (tp*32 pixels) on a 2 x 2 consumer grid, nst-deep ring
 int ladi_launch_igemm_lc(const IGemmArgs& a, int tq, int tp, int nst, int batch, hipStream_t st);
 
+// ---- igemm_halo.hip: halo-resident 3x3 convolution, workgroup tile (64 tq) x (128 tp), nxb halo buffers
+bool ladi_igemm_halo_eligible(const IGemmArgs& a, int batch);
+int ladi_launch_igemm_halo(const IGemmArgs& a, int tq, int tp, int nxb, int batch, hipStream_t st);
+
 // ---- linear_xs.hip: X-stationary kernel for 1x1 layers with K = 320 / 640 (reached through ladi_launch_igemm cfg 23..27)
 bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs);
 int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st);

@@ -25,7 +25,10 @@ NEW_RING = [39, 40, 41, 42, 43, 44, 45, 47, 48]      # round 3: one-wave-per-SIM
 NEW_IGEMM8 = [54, 55, 56, 57, 58, 62, 63, 64, 65, 66, 67, 68]   # + the loader / consumer kernel (igemm_lc.hip)                      # round 3: more shapes of the phase-staggered 8-wave pipeline
 
 
-@pytest.mark.parametrize("cfg", [19, 20, 21, 22, 32, 33] + NEW_RING + NEW_IGEMM8)
+HALO = [74, 75, 76, 77, 78, 84, 85]                            # round 3: halo-resident 3x3 convolution (igemm_halo.hip)
+
+
+@pytest.mark.parametrize("cfg", [19, 20, 21, 22, 32, 33] + NEW_RING + NEW_IGEMM8 + HALO)
 def test_conv3x3_eight_wave_tiles(cfg):
     """large workgroup tile shapes (8 waves, or 4 waves with one wave per SIMD), ragged pixel count, residual + statistics-free epilogue"""
     N, cin, cout, h, w = 3, 128, 320, 20, 13
@@ -125,7 +128,7 @@ def test_conv3x3_bias_res_temb(cin, cout, h, w, cfg):
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 34, 35, 36, 37, 38, 46, 49, 50, 51, 52, 53, 59, 60, 61, 69, 70, 71, 72, 73])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 34, 35, 36, 37, 38, 46, 49, 50, 51, 52, 53, 59, 60, 61, 69, 70, 71, 72, 73, 79, 80, 81, 82, 83, 86, 87])
 def test_conv3x3_split_k(cfg):
     """split-K variants (fp32 partial slices + reduce pass that applies the epilogue) on a few-tile / deep-K problem"""
     N, cin, cout, h, w = 2, 512, 192, 8, 6
@@ -181,7 +184,7 @@ def test_igemm8_is_race_free_and_deterministic(cfg):
     assert U.rel_l2(U.to_nchw(first), F.conv2d(x, wt, b, padding=1)) < TOL
 
 
-@pytest.mark.parametrize("cfg", [7, 9, 32, 39, 40, 45, 54, 56, 62, 64, 65, 68])
+@pytest.mark.parametrize("cfg", [7, 9, 32, 39, 40, 45, 54, 56, 62, 64, 65, 68, 74, 76, 77, 84, 85])
 def test_fused_output_statistics(cfg):
     """per-channel partial statistics of the output (sum, sum of squares of the fp16-rounded values) written by the epilogue for the
     consuming GroupNorm: rows of [Q][2] per (TP*32)-pixel block -- 96-pixel blocks for the 320x192 / 256x192 tiles.  Summed over all rows
@@ -207,6 +210,39 @@ def test_fused_output_statistics(cfg):
     o = out.float().reshape(-1, cout)
     tot = stats.sum(0).cpu()
     assert U.rel_l2(tot[:, 0], o.sum(0).cpu()) < 1e-4 and U.rel_l2(tot[:, 1], (o * o).sum(0).cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("cfg", HALO + [79, 80, 86])
+def test_conv3x3_halo_resident(cfg):
+    """the halo-resident 3x3 convolution: the nine taps are applied when the B fragments are read from ONE staged pixel range, so what
+    must be right is the tap shift / validity logic at image edges (left / right wrap-around, top / bottom rows, sample boundaries), the
+    two-source K loop, ragged tiles, several channel chunks (double-buffered halo tile) and the widest supported image (W = 48).
+    Repeated runs must be bit-identical (race screen of the counted waits)."""
+    lib = _lib.load()
+    for (N, c0, c1, cout, h, w_, act, seed) in ((3, 128, 0, 320, 20, 13, "none", 70), (2, 192, 64, 192, 9, 48, "silu", 74), (5, 64, 0, 96, 6, 6, "none", 78),
+                                               (1, 320, 0, 320, 64, 48, "none", 82)):
+        xa = _rand((N, c0, h, w_), seed)
+        xb = _rand((N, c1, h, w_), seed + 1) if c1 else None
+        wt, b = _rand((cout, c0 + c1, 3, 3), seed + 2, 1 / math.sqrt(9 * (c0 + c1))), _rand((cout,), seed + 3, 0.1)
+        res = _rand((N, cout, h, w_), seed + 4)
+        xin = torch.cat([xa, xb], 1) if c1 else xa
+        ref = F.conv2d(xin, wt, b, padding=1)
+        ref = (F.silu(ref) if act == "silu" else ref) + res
+        args = dict(bias=b, act=act, res0=U.nhwc16(res), cfg=cfg)
+        if c1:
+            args["x2"] = U.nhwc16(xb)
+        Xa, Wp = U.nhwc16(xa), U.pack_conv_weight(wt)
+        y = U.igemm(Xa, Wp, cout, **args)
+        assert U.rel_l2(U.to_nchw(y), ref) < TOL, (cfg, N, c0, c1, cout, h, w_)
+        for _ in range(5):
+            assert torch.equal(U.igemm(Xa, Wp, cout, **args), y)
+    # not a 3x3 stride-1 convolution / too wide an image: refused, never mis-computed
+    x, w1 = _rand((1, 64, 8, 8), 90), _rand((64, 64, 1, 1), 91)
+    with pytest.raises(AssertionError):
+        U.igemm(U.nhwc16(x), U.pack_conv_weight(w1), 64, ksize=1, cfg=cfg)
+    xw, w3 = _rand((1, 64, 4, 64), 92), _rand((64, 64, 3, 3), 93)
+    with pytest.raises(AssertionError):
+        U.igemm(U.nhwc16(xw), U.pack_conv_weight(w3), 64, cfg=cfg)
 
 
 def test_conv3x3_stride2_pad1_and_asym():
