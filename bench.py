@@ -179,12 +179,12 @@ def traffic_measured(symbol, extra_args):
 
 
 def traffic_committed(symbol):
-    """profiles/r02_pmc_{fetch,write}_size.txt, valid only for the library build they were taken with (first line: # lib_digest=...)"""
+    """profiles/r03_pmc_{fetch,write}_size.txt, valid only for the library build they were taken with (first line: # lib_digest=...)"""
     vals = {}
     for tag in ("fetch", "write"):
-        path = os.path.join(ROOT, "profiles", "r02_pmc_%s_size.txt" % tag)
+        path = os.path.join(ROOT, "profiles", "r03_pmc_%s_size.txt" % tag)
         if not os.path.exists(path):
-            return None, "no committed PMC pass (profiles/r02_pmc_%s_size.txt)" % tag
+            return None, "no committed PMC pass (profiles/r03_pmc_%s_size.txt)" % tag
         lines = open(path).read().splitlines()
         m = re.match(r"# lib_digest=(\w+)", lines[0]) if lines else None
         if not m or m.group(1) != lib_digest():
@@ -196,7 +196,7 @@ def traffic_committed(symbol):
     if len(vals) != 2:
         return None, "kernel %s not in the committed PMC passes" % symbol
     return {"bytes_per_launch": round(2.0 * vals["fetch"] + vals["write"]), "fetch_bytes_x2": round(2.0 * vals["fetch"]),
-            "write_bytes": round(vals["write"]), "source": "profiles/r02_pmc_{fetch,write}_size.txt (same library digest; avg over all launches "
+            "write_bytes": round(vals["write"]), "source": "profiles/r03_pmc_{fetch,write}_size.txt (same library digest; avg over all launches "
             "of this kernel in `bench.py --roofline-only`)"}, None
 
 
@@ -406,14 +406,20 @@ def main():
         unet.time_forward(n, h, w, a.roofline_iters)   # 1 warm-up + roofline_iters timed forwards, all recorded
         lib.ladi_profile_igemm_enable(0)
         NCFG, SYMBOL = igemm_symbols(lib)
+        # per-launch records grouped by the EXACT kernel symbol (as rocprofv3 prints it; the X-stationary kernel has one per <KH, PB, MODE, LN>)
+        sbuf = ctypes.create_string_buffer(1 << 16)
+        lib.ladi_profile_igemm_symbols(sbuf, len(sbuf))
+        sym = {}
+        for line in sbuf.value.decode().splitlines():
+            name, ms_, fl_, cnt_ = line.split("\t")
+            sym[name] = dict(ms=float(ms_), flop=float(fl_), launches=int(cnt_), cfgs=[])
         prof = (ctypes.c_double * (3 * (NCFG + 1)))()
         lib.ladi_profile_igemm_collect(prof, 3 * (NCFG + 1))
-        sym = {}
         for c_ in range(1, NCFG + 1):
-            ms, fl, cnt = prof[c_ * 3], prof[c_ * 3 + 1], prof[c_ * 3 + 2]
-            if cnt > 0:
-                s = sym.setdefault(SYMBOL.get(c_, "cfg%d" % c_), dict(ms=0.0, flop=0.0, launches=0, cfgs=[]))
-                s["ms"] += ms; s["flop"] += fl; s["launches"] += int(cnt); s["cfgs"].append(c_)
+            if prof[c_ * 3 + 2] > 0:
+                for name in sym:
+                    if name == SYMBOL.get(c_) or (SYMBOL.get(c_) == "linear_xs_kernel" and name.startswith("linear_xs_kernel")):
+                        sym[name]["cfgs"].append(c_)
         if sym:
             dom = max(sym, key=lambda k: sym[k]["ms"])
             d = sym[dom]

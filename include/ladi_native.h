@@ -251,6 +251,9 @@ int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* 
 void ladi_igemm_set_autotune(int on);
 void ladi_profile_igemm_enable(int on);
 int ladi_profile_igemm_collect(double* out, int n_out);
+/* the same records grouped by the exact kernel symbol rocprofv3 reports (the X-stationary kernel has several): text lines
+ * "symbol\tms\tflop\tlaunches\n" into buf (at most n bytes, NUL-terminated); returns the untruncated length.  Call BEFORE collect(). */
+int ladi_profile_igemm_symbols(char* buf, int n);
 /* number of tile configurations (valid ids 1..count) and the kernel symbol configuration `cfg` launches, as rocprofv3 names it
  * (split-K variants share the symbol of their base tile); "" for an unknown id.  The string is owned by the library. */
 int ladi_igemm_cfg_count(void);

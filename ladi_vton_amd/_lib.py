@@ -131,6 +131,7 @@ SIGNATURES = {
     "ladi_igemm_set_autotune": (None, [c_int]),
     "ladi_profile_igemm_enable": (None, [c_int]),
     "ladi_profile_igemm_collect": (c_int, [POINTER(ctypes.c_double), c_int]),
+    "ladi_profile_igemm_symbols": (c_int, [ctypes.c_char_p, c_int]),
     "ladi_igemm_cfg_count": (c_int, []),
     "ladi_igemm_cfg_symbol_name": (ctypes.c_char_p, [c_int]),
     "ladi_op_igemm": (c_int, [POINTER(IGemmDesc), c_int, c_int, _P]),

@@ -27,6 +27,7 @@
 #include <vector>
 #include <unordered_map>
 #include <map>
+#include <array>
 #include <string>
 #include <cstdio>
 #include <cstdlib>
@@ -281,7 +282,7 @@ int launch_base(int cfg, const IGemmArgs& a, int batch, hipStream_t st) {
     }
 }
 
-struct ProfRec { hipEvent_t e0, e1; int cfg; double flops; int P, Q, K, ks; };
+struct ProfRec { hipEvent_t e0, e1; int cfg; double flops; int P, Q, K, ks; char sym[56]; };
 bool g_prof = false;
 std::vector<ProfRec> g_recs;
 
@@ -510,6 +511,8 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     if (prof) {
         if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) return -12;
         rec.cfg = cfg; rec.P = a.P; rec.Q = a.Q; rec.K = a.K; rec.ks = a.ksize;
+        if (kCfg[cfg].base == 23) ladi_linear_xs_symbol(a, kCfg[cfg].tp, rec.sym, (int)sizeof(rec.sym));
+        else snprintf(rec.sym, sizeof(rec.sym), "%s", cfg_symbol(cfg).c_str());
         rec.flops = 2.0 * (double)a.P * (double)a.Q * (double)a.K * (double)batch;
         (void)hipEventRecord(rec.e0, st);
     }
@@ -535,6 +538,24 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
 void ladi_igemm_profile_enable(int on) { g_prof = on != 0; }
 void ladi_igemm_autotune(int on) { g_autotune = on != 0; }
 int ladi_igemm_tuned_count() { return (int)g_tuned.size(); }
+int ladi_igemm_profile_symbols(char* buf, int n) {
+    std::map<std::string, std::array<double, 3>> by;
+    for (auto& r : g_recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return -2;
+        auto& e = by[r.sym];
+        e[0] += ms; e[1] += r.flops; e[2] += 1.0;
+    }
+    std::string out;
+    for (auto& kv : by) {
+        char line[160];
+        snprintf(line, sizeof(line), "%s\t%.6f\t%.6e\t%d\n", kv.first.c_str(), kv.second[0], kv.second[1], (int)kv.second[2]);
+        out += line;
+    }
+    if (n > 0) { snprintf(buf, (size_t)n, "%s", out.c_str()); }
+    return (int)out.size();
+}
 // out[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP (2*P*Q*K), launches} for cfg 1..NCFG (index 0 = all); clears the records
 int ladi_igemm_profile_collect(double* out, int n_out) {
     for (int i = 0; i < n_out; ++i) out[i] = 0.0;

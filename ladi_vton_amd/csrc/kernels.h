@@ -29,6 +29,7 @@ int ladi_launch_igemm_halo(const IGemmArgs& a, int tq, int tp, int nxb, int batc
 // ---- linear_xs.hip: X-stationary kernel for 1x1 layers with K = 320 / 640 (reached through ladi_launch_igemm cfg 23..27)
 bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs);
 int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st);
+void ladi_linear_xs_symbol(const IGemmArgs& a, int pb, char* out, int n);
 
 // ---- norm.hip
 // GroupNorm in three stages (all atomics-free): per-channel partial statistics rows [rows][C][2] (written by the producing
@@ -180,3 +181,6 @@ int ladi_igemm_tuned_count();
 int ladi_igemm_num_cfgs();
 const char* ladi_igemm_cfg_symbol(int cfg);
 int ladi_igemm_profile_collect(double* out, int n_out);
+// the same records grouped by kernel SYMBOL (exact rocprofv3 name): lines "symbol\tms\tflop\tlaunches\n" into buf (truncated at n); does
+// NOT clear the records (call before ladi_igemm_profile_collect)
+int ladi_igemm_profile_symbols(char* buf, int n);

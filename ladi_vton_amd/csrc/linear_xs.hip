@@ -19,6 +19,7 @@
 // P a multiple of the workgroup's pixel panel; Q a multiple of 32 (64 for GEGLU) split evenly over gridDim.y.
 #include "common.h"
 #include "kernels.h"
+#include <cstdio>
 
 namespace {
 
@@ -332,6 +333,13 @@ bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs) {
     if ((size_t)a.Q * a.K * 2 >= 0x7FFFFFFFull) return false;
     if (XS_NST * XS_STAGE + 4 * (res ? 2 * XS_RPATCH : XS_PATCH) + (a.Q / qs) * 2 > XS_SMEM_MAX) return false;
     return true;
+}
+
+// the kernel symbol (as rocprofv3 prints it) ladi_launch_linear_xs launches for these arguments: <KH, PB, MODE, LN>
+void ladi_linear_xs_symbol(const IGemmArgs& a, int pb, char* out, int n) {
+    const int kh = a.K == 320 ? 1 : 2, mode = a.act == LADI_ACT_GEGLU ? 2 : (a.res0 ? 1 : 0);
+    const int pbb = (mode == 0 && a.K == 320 && pb == 2) ? 2 : 1;
+    snprintf(out, (size_t)n, "linear_xs_kernel<%d, %d, %d, %s>", kh, pbb, mode, a.ln_gamma ? "true" : "false");
 }
 
 int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st) {

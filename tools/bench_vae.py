@@ -1,4 +1,4 @@
-"""VAE encode / EMASC / VAE decode stages alone (no hipGraph), the command behind profiles/r02_vae_*: per-stage time, algorithmic
+"""VAE encode / EMASC / VAE decode stages alone (no hipGraph), the command behind profiles/r03_vae_*: per-stage time, algorithmic
 TFLOP/s and fused-minimal HBM GB/s (SURVEY.md §8d per-image figures), and -- under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE -- the
 per-kernel HBM bytes of the conv / GroupNorm / attention kernels of these stages.
 python tools/bench_vae.py [--batch 8] [--height 512 --width 384] [--iters 3]"""
