@@ -19,11 +19,12 @@
 
 namespace {
 
-constexpr int KV_STAGE = 128;        // keys staged per barrier pair (two 64-key compute sub-tiles)
-constexpr int VT_LD = KV_STAGE + 4;  // halves per V^T row (8-byte aligned rows, conflict-free 8-byte column reads)
+constexpr int KV_STAGE = 128;        // keys staged per barrier (two 64-key compute sub-tiles)
 constexpr float RESCALE_THR = 8.0f;  // defer the O/l rescale until the running max grows by more than 2^8 (P <= 256 fits fp16)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __fp16 f16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));   // operand type of the transposed LDS read builtin
+typedef __attribute__((address_space(3))) f16x4v* lds_f16x4_t;
 template <int V> struct SubIdx { static constexpr int value = V; };
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
@@ -31,8 +32,10 @@ __device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((ch
 // MFMA for the long self-attention layers; QB = 1 keeps more blocks in flight for short sequences)
 template <int QB>
 __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) h16 sKbuf[2 * KV_STAGE * 64];   // double buffer: filled by LDS-DMA one stage ahead
-    __shared__ __attribute__((aligned(16))) h16 sVt[64 * VT_LD];
+    // dynamic LDS (64 KiB): K double buffer | V double buffer, both filled by LDS-DMA one stage ahead
+    extern __shared__ __attribute__((aligned(16))) char fa_smem[];
+    h16* sKbuf = reinterpret_cast<h16*>(fa_smem);                              // [2][KV_STAGE][64]
+    h16* sVbuf = sKbuf + 2 * KV_STAGE * 64;                                    // [2][KV_STAGE][64]
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -82,56 +85,52 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
             for (int r = 0; r < 16; ++r) o_acc[qb][d][r] = 0.f;
     }
 
-    // staging.  K: 4 x 16 B per thread by LDS-DMA (buffer_load ... lds) straight into the next sK buffer; the LDS image of a DMA
-    // is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk (same scheme as igemm.hip).  V: one 4-key x 8-d
-    // micro-tile per thread through registers (transposed on the way into sVt).
+    // staging (round 3).  K AND V: 4 x 16 B per thread and tensor by LDS-DMA (buffer_load ... lds) straight into the next stage's
+    // buffers, row-major [key][64 d] like global memory.  The LDS image of a DMA is lane-linear, so the XOR swizzle is applied to
+    // the per-lane SOURCE chunk (same scheme as igemm.hip): K chunk ^= (row >> 1) & 7 (read back as 16-byte B fragments), V chunk ^=
+    // row & 7 (read back TRANSPOSED by ds_read_b64_tr_b16, which hands a lane four keys of one d: the V^T fragment of the PV
+    // product without the register transposition that cost 21 % of the round-2 kernel; profiles/r03_attention_ablation.txt).
     const int k_r0 = tid >> 3, k_c8 = tid & 7;
     const int k_clog = k_c8 ^ ((k_r0 >> 1) & 7);     // rows k_r0 + 32 i share (row >> 1) & 7
+    const int v_clog = k_c8 ^ (k_r0 & 7);            // rows k_r0 + 32 i share row & 7
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(kp), 0, 0x7FFFFFFF, 0x00020000);
-    const int v_quad = tid & 31, v_oct = tid >> 5;   // keys 4*quad.., d = 8*oct..
-    uint4 vst0, vst1, vst2, vst3;   // named scalars: arrays captured by lambdas were demoted to scratch
-
-#define FA_KDMA(buf, i)                                                                                    \
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(vp), 0, 0x7FFFFFFF, 0x00020000);
+    // transposed read: in each 16-lane group lane k hands in the address of 4 d of key (k >> 2); it gets back d = (its index) of 4
+    // keys (measured layout: tools/experiments/ds_read_tr16.hip).  Group g: d half g & 1, key half hh = g >> 1 (keys +4 hh, the
+    // accumulator-row permutation of the S^T tile).  The swizzle term row & 7 = 4 hh + (k >> 2) is a lane constant.
+    int tr_off[2];
+    {
+        const int tk = lane & 15, trow = 4 * hh + (tk >> 2), c0 = 2 * ((lane >> 4) & 1) + ((tk & 3) >> 1);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) tr_off[d] = trow * 64 + (((d * 4 + c0) ^ trow) << 3) + 4 * (tk & 1);
+    }
+#define FA_DMA(rsrc, ld, clog, sbuf, buf, i)                                                               \
     {                                                                                                      \
         const int key = key0_ + k_r0 + 32 * (i);                                                           \
-        const int kc = key < a.Nk ? key : a.Nk - 1; /* clamp (masked later) instead of branching */        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(reinterpret_cast<char*>(sKbuf) + (buf) * (KV_STAGE * 128) + (i) * 4096 + wave * 1024), \
-                                                 16, (unsigned)((kc * a.ldk + k_clog * 8) * 2), 0, 0, 0);  \
+        const int kc = key < a.Nk ? key : a.Nk - 1; /* clamp: scores of keys >= Nk are masked, P = 0 exactly */ \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(reinterpret_cast<char*>(sbuf) + (buf) * (KV_STAGE * 128) + (i) * 4096 + wave * 1024), \
+                                                 16, (unsigned)((kc * (ld) + (clog) * 8) * 2), 0, 0, 0);   \
     }
-#define FA_VLOAD(dst, i)                                                                                   \
-    {                                                                                                      \
-        const int key = key0_ + v_quad * 4 + (i);                                                          \
-        dst = make_uint4(0, 0, 0, 0); /* V rows past Nk must be exact zeros (0 * garbage could be NaN) */  \
-        if (key < a.Nk) dst = *reinterpret_cast<const uint4*>(vp + (size_t)key * a.ldv + v_oct * 8);       \
-    }
-#define FA_GLOAD(k0v, buf)                                                                                 \
+#define FA_STAGE(k0v, buf)                                                                                 \
     {                                                                                                      \
         const int key0_ = (k0v);                                                                           \
-        FA_KDMA(buf, 0) FA_KDMA(buf, 1) FA_KDMA(buf, 2) FA_KDMA(buf, 3)                                    \
-        FA_VLOAD(vst0, 0) FA_VLOAD(vst1, 1) FA_VLOAD(vst2, 2) FA_VLOAD(vst3, 3)                            \
-    }
-#define FA_VROW(e, comp, odd)                                                                              \
-    {                                                                                                      \
-        uint2 t_;                                                                                          \
-        if (odd) { t_.x = (vst0.comp >> 16) | (vst1.comp & 0xffff0000u); t_.y = (vst2.comp >> 16) | (vst3.comp & 0xffff0000u); } \
-        else { t_.x = (vst0.comp & 0xffffu) | (vst1.comp << 16); t_.y = (vst2.comp & 0xffffu) | (vst3.comp << 16); }           \
-        *reinterpret_cast<uint2*>(sVt + (v_oct * 8 + (e)) * VT_LD + v_quad * 4) = t_;                      \
-    }
-#define FA_LSTORE()                                                                                        \
-    {                                                                                                      \
-        FA_VROW(0, x, 0) FA_VROW(1, x, 1) FA_VROW(2, y, 0) FA_VROW(3, y, 1)                                \
-        FA_VROW(4, z, 0) FA_VROW(5, z, 1) FA_VROW(6, w, 0) FA_VROW(7, w, 1)                                \
+        FA_DMA(rk, a.ldk, k_clog, sKbuf, buf, 0) FA_DMA(rk, a.ldk, k_clog, sKbuf, buf, 1)                  \
+        FA_DMA(rk, a.ldk, k_clog, sKbuf, buf, 2) FA_DMA(rk, a.ldk, k_clog, sKbuf, buf, 3)                  \
+        FA_DMA(rv, a.ldv, v_clog, sVbuf, buf, 0) FA_DMA(rv, a.ldv, v_clog, sVbuf, buf, 1)                  \
+        FA_DMA(rv, a.ldv, v_clog, sVbuf, buf, 2) FA_DMA(rv, a.ldv, v_clog, sVbuf, buf, 3)                  \
     }
 
+    // ONE barrier per 128-key stage: stage t multiplies from buffers t & 1 while the DMA of stage t + 1 fills the other pair.  The
+    // barrier at the top of a stage says: my K/V pieces of stage t have landed (vmcnt), everybody's have (barrier), and everybody
+    // is done reading the buffers of stage t - 1, which are the ones refilled now.
     const int nstages = (a.Nk + KV_STAGE - 1) / KV_STAGE;
-    FA_GLOAD(0, 0)
+    FA_STAGE(0, 0)
     for (int t = 0; t < nstages; ++t) {
         const h16* sK = sKbuf + (t & 1) * (KV_STAGE * 64);
-        __syncthreads();  // previous stage fully consumed (sVt and the other sK buffer are free)
-        FA_LSTORE()
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's K DMA has landed (the compiler does not track DMA -> LDS)
+        const h16* sV = sVbuf + (t & 1) * (KV_STAGE * 64);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler does not track DMA -> LDS
         __syncthreads();
-        if (t + 1 < nstages) FA_GLOAD((t + 1) * KV_STAGE, (t + 1) & 1)
+        if (t + 1 < nstages) FA_STAGE((t + 1) * KV_STAGE, (t + 1) & 1)
         auto process = [&](auto SubC) __attribute__((always_inline)) {
             constexpr int sub = decltype(SubC)::value;
             const int key0 = t * KV_STAGE + sub * 64;
@@ -213,15 +212,15 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
-                    const int kofs = sub * 64 + kb * 32 + k2 * 16 + 4 * hh;
+                    const int kbase = sub * 64 + kb * 32 + k2 * 16;   // + 4 hh + (k >> 2) sits in tr_off
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
-                        const h16* vrow = sVt + (d * 32 + l31) * VT_LD + kofs;
-                        const h16x4 lo = *reinterpret_cast<const h16x4*>(vrow);
-                        const h16x4 hi = *reinterpret_cast<const h16x4*>(vrow + 8);
+                        const h16* vb = sV + kbase * 64 + tr_off[d];
+                        const f16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_t)vb);
+                        const f16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_t)(vb + 8 * 64));
                         h16x8 vf;
-                        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                        vf[0] = (h16)lo[0]; vf[1] = (h16)lo[1]; vf[2] = (h16)lo[2]; vf[3] = (h16)lo[3];
+                        vf[4] = (h16)hi[0]; vf[5] = (h16)hi[1]; vf[6] = (h16)hi[2]; vf[7] = (h16)hi[3];
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb)
                             o_acc[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kb][k2], o_acc[qb][d], 0, 0, 0);
@@ -574,12 +573,16 @@ int ladi_launch_flash_attn64(const AttnArgs& a, hipStream_t st) {
     AttnArgs b = a;
     static const bool no_xcd = getenv("LADI_ATTN_NOXCD") != nullptr;   // A/B switch for the XCD-aware mapping
     b.xcd_map = no_xcd ? 0 : 1;
+    constexpr int kSmem = 4 * KV_STAGE * 64 * 2;   // 64 KiB: two workgroups per CU
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn64_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess &&
+                                hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn64_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess;
+    if (!attr_ok) return -12;
     if (qb2) {
         b.qtiles = (a.Nq + 255) / 256;
-        hipLaunchKernelGGL(flash_attn64_kernel<2>, dim3((unsigned)(b.qtiles * a.heads * a.n)), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(flash_attn64_kernel<2>, dim3((unsigned)(b.qtiles * a.heads * a.n)), dim3(256), kSmem, st, b);
     } else {
         b.qtiles = (a.Nq + 127) / 128;
-        hipLaunchKernelGGL(flash_attn64_kernel<1>, dim3((unsigned)(b.qtiles * a.heads * a.n)), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(flash_attn64_kernel<1>, dim3((unsigned)(b.qtiles * a.heads * a.n)), dim3(256), kSmem, st, b);
     }
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
