@@ -160,17 +160,16 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
             h16x8 pf[QB][2][2];
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                float mt = -1.0e30f;   // tile maximum relative to m_run
-                if (key0 + 64 > a.Nk || a.causal) {
+                float mt = -1.0e30f;   // maximum of THIS LANE's 32 keys relative to m_run (the other k-half of the query sits in lane ^ 32)
+                if (key0 + 64 > a.Nk || a.causal) {   // wave-uniform; the mask compares against compile-time key offsets
                     // causal (CLIP text encoder): query i attends to keys <= i; key 0 is visible to every query, so the first
                     // sub-tile always yields a finite reference
-                    const int klim = a.causal ? min(a.Nk, qbase + qb * 32 + l31 + 1) : a.Nk;
+                    const int lim = (a.causal ? min(a.Nk, qbase + qb * 32 + l31 + 1) : a.Nk) - key0 - 4 * hh;   // compile-time key offsets below
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                            const float sv = (key < klim) ? s_acc[qb][kb][r] : -1.0e30f;
+                            const float sv = (kb * 32 + (r & 3) + 8 * (r >> 2) < lim) ? s_acc[qb][kb][r] : -1.0e30f;
                             s_acc[qb][kb][r] = sv;
                             mt = fmaxf(mt, sv);
                         }
@@ -180,9 +179,10 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
 #pragma unroll
                         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s_acc[qb][kb][r]);
                 }
-                mt = fmaxf(mt, __shfl_xor(mt, 32));
-                // deferred rescale (wave-uniform decision): everything still at the old reference is scaled exactly once
+                // deferred rescale (wave-uniform decision): everything still at the old reference is scaled exactly once.  The two
+                // lanes of a query exchange their maxima only here (ds_bpermute round trip), not on the common path.
                 if (first || __any(mt > RESCALE_THR)) {
+                    mt = fmaxf(mt, __shfl_xor(mt, 32));
                     const float delta = first ? mt : fmaxf(mt, 0.f);
                     const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // nothing accumulated yet on the first tile
                     m_run[qb] += delta;
