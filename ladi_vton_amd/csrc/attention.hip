@@ -25,6 +25,7 @@ constexpr float RESCALE_THR = 8.0f;  // defer the O/l rescale until the running 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __fp16 f16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));   // operand type of the transposed LDS read builtin
 typedef __attribute__((address_space(3))) f16x4v* lds_f16x4_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int V> struct SubIdx { static constexpr int value = V; };
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
@@ -74,9 +75,16 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
     }
 
     f32x16 o_acc[QB][2];
+    // The reference m_run is kept INTEGER-valued (rounded up when it moves), so -m_run = -(1024 a) - b with |b| <= 512 is exact in two
+    // fp16 values, and it enters the score accumulators through one extra MFMA k-step (K side: ones in k slots 0 and 1) instead of 16
+    // v_mov per accumulator: the kernel is VALU-bound (10 VALU per MFMA before this change, PMC round 3), the MFMA pipe has the room.
+    h16x8 ones_f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hh == 0) { ones_f[0] = (h16)1.f; ones_f[1] = (h16)1.f; }
+    h16x8 mneg[QB];
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
+        mneg[qb] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
         m_run[qb] = 0.f;   // reference offset of the exponent; set by the first sub-tile
         l_run[qb] = 0.f;
 #pragma unroll
@@ -93,8 +101,16 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
     const int k_r0 = tid >> 3, k_c8 = tid & 7;
     const int k_clog = k_c8 ^ ((k_r0 >> 1) & 7);     // rows k_r0 + 32 i share (row >> 1) & 7
     const int v_clog = k_c8 ^ (k_r0 & 7);            // rows k_r0 + 32 i share row & 7
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(kp), 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(vp), 0, 0x7FFFFFFF, 0x00020000);
+    auto make_rsrc = [](const h16* p) {   // raw buffer descriptor (base, stride 0, 2 GiB - 1 records, dword data format) in SGPRs
+        const unsigned long long b = (unsigned long long)p;
+        u32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+        r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+        r[2] = 0x7FFFFFFFu;
+        r[3] = 0x00020000u;
+        return r;
+    };
+    const u32x4 rk = make_rsrc(kp), rv = make_rsrc(vp);
     // transposed read: in each 16-lane group lane k hands in the address of 4 d of key (k >> 2); it gets back d = (its index) of 4
     // keys (measured layout: tools/experiments/ds_read_tr16.hip).  Group g: d half g & 1, key half hh = g >> 1 (keys +4 hh, the
     // accumulator-row permutation of the S^T tile).  The swizzle term row & 7 = 4 hh + (k >> 2) is a lane constant.
@@ -104,20 +120,26 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
 #pragma unroll
         for (int d = 0; d < 2; ++d) tr_off[d] = trow * 64 + (((d * 4 + c0) ^ trow) << 3) + 4 * (tk & 1);
     }
-#define FA_DMA(rsrc, ld, clog, sbuf, buf, i)                                                               \
+    // The DMA is issued from inline asm on purpose: with the builtin the compiler knows an LDS-DMA is in flight and, unable to prove
+    // that the transposed reads of THIS stage do not alias the buffers being filled for the next one, puts s_waitcnt vmcnt(0) in
+    // front of the first V read of the stage: the prefetch then costs a full memory round trip in the middle of every stage.
+    // Synchronisation is explicit instead (vmcnt(0) + barrier at the top of each stage).
+    const unsigned lds_k0 = (unsigned)(size_t)(lds_ptr_t)sKbuf, lds_v0 = (unsigned)(size_t)(lds_ptr_t)sVbuf;
+#define FA_DMA(rsrc, ld, clog, lds0, buf, i)                                                               \
     {                                                                                                      \
         const int key = key0_ + k_r0 + 32 * (i);                                                           \
         const int kc = key < a.Nk ? key : a.Nk - 1; /* clamp: scores of keys >= Nk are masked, P = 0 exactly */ \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(reinterpret_cast<char*>(sbuf) + (buf) * (KV_STAGE * 128) + (i) * 4096 + wave * 1024), \
-                                                 16, (unsigned)((kc * (ld) + (clog) * 8) * 2), 0, 0, 0);   \
+        const unsigned m0v = __builtin_amdgcn_readfirstlane((lds0) + (buf) * (KV_STAGE * 128) + (i) * 4096 + wave * 1024); \
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                          \
+                     :: "s"(m0v), "v"((unsigned)((kc * (ld) + (clog) * 8) * 2)), "s"(rsrc) : "memory"); /* m0 is not used by anything else in this kernel */ \
     }
 #define FA_STAGE(k0v, buf)                                                                                 \
     {                                                                                                      \
         const int key0_ = (k0v);                                                                           \
-        FA_DMA(rk, a.ldk, k_clog, sKbuf, buf, 0) FA_DMA(rk, a.ldk, k_clog, sKbuf, buf, 1)                  \
-        FA_DMA(rk, a.ldk, k_clog, sKbuf, buf, 2) FA_DMA(rk, a.ldk, k_clog, sKbuf, buf, 3)                  \
-        FA_DMA(rv, a.ldv, v_clog, sVbuf, buf, 0) FA_DMA(rv, a.ldv, v_clog, sVbuf, buf, 1)                  \
-        FA_DMA(rv, a.ldv, v_clog, sVbuf, buf, 2) FA_DMA(rv, a.ldv, v_clog, sVbuf, buf, 3)                  \
+        FA_DMA(rk, a.ldk, k_clog, lds_k0, buf, 0) FA_DMA(rk, a.ldk, k_clog, lds_k0, buf, 1)                \
+        FA_DMA(rk, a.ldk, k_clog, lds_k0, buf, 2) FA_DMA(rk, a.ldk, k_clog, lds_k0, buf, 3)                \
+        FA_DMA(rv, a.ldv, v_clog, lds_v0, buf, 0) FA_DMA(rv, a.ldv, v_clog, lds_v0, buf, 1)                \
+        FA_DMA(rv, a.ldv, v_clog, lds_v0, buf, 2) FA_DMA(rv, a.ldv, v_clog, lds_v0, buf, 3)                \
     }
 
     // ONE barrier per 128-key stage: stage t multiplies from buffers t & 1 while the DMA of stage t + 1 fills the other pair.  The
@@ -143,9 +165,10 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
-                    const float init = -m_run[qb];
+                    f32x16 z;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s_acc[qb][kb][r] = init;
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones_f, mneg[qb], z, 0, 0, 0);   // = -m_run of the lane's query, exactly
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
@@ -183,9 +206,15 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 2) void flash_attn64_kernel(cons
                 // lanes of a query exchange their maxima only here (ds_bpermute round trip), not on the common path.
                 if (first || __any(mt > RESCALE_THR)) {
                     mt = fmaxf(mt, __shfl_xor(mt, 32));
-                    const float delta = first ? mt : fmaxf(mt, 0.f);
+                    // integer steps; |m_run| <= 64000 keeps the fp16 pair exact (scores of that size mean overflowed fp16 inputs anyway)
+                    float delta = ceilf(first ? mt : fmaxf(mt, 0.f));
+                    delta = fminf(fmaxf(m_run[qb] + delta, -64000.f), 64000.f) - m_run[qb];
                     const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // nothing accumulated yet on the first tile
                     m_run[qb] += delta;
+                    {
+                        const float hi = 1024.f * rintf(m_run[qb] * (1.f / 1024.f));
+                        if (hh == 0) { mneg[qb][0] = (h16)(-hi); mneg[qb][1] = (h16)(hi - m_run[qb]); }
+                    }
                     l_run[qb] *= alpha;
 #pragma unroll
                     for (int d = 0; d < 2; ++d)
