@@ -445,6 +445,38 @@ def test_flash_attention_forced_rescale_two_query_blocks(lib):
     assert U.rel_l2(O[3, 32:64, 64:128].float().cpu(), ref[3, 32:64, 64:128]) < 3e-3
 
 
+@pytest.mark.parametrize("mode", ["wide", "negative", "positive"])
+@pytest.mark.parametrize("n,heads,Nq,Nk", [(1, 2, 96, 200), (8, 5, 2560, 384)])   # short-sequence form / 64-queries-per-wave form
+def test_flash_attention_large_logits(lib, mode, n, heads, Nq, Nk):
+    """the running reference of the online softmax enters the score accumulators as an exact fp16 pair (-1024 a, -b) through one MFMA
+    k-step (attention.hip): scores of +-10^3 and beyond (log2 units, far outside anything the UNet produces) must neither overflow
+    nor lose the reference.  Q, K, V are column slices of one [n, T, 3C] buffer (the layout of the fused QKV projection)."""
+    C = heads * 64
+    T = max(Nq, Nk)
+    g = torch.Generator().manual_seed(77)
+    buf = torch.randn((n, T, 3 * C), generator=g)
+    if mode == "wide":
+        buf[..., :2 * C] *= 20.0                                    # logits ~ N(0, 400^2): one-hot rows, references of both signs
+    else:
+        sign = -1.0 if mode == "negative" else 1.0
+        buf[..., :C] = buf[..., :C].abs() * 6.0 + 12.0              # q > 0
+        buf[..., C:2 * C] = sign * (buf[..., C:2 * C].abs() * 6.0 + 12.0)   # every logit ~ -+ 2500 (natural units)
+    buf = buf.half()
+    q, k, v = (buf[:, :Nq, :C].float(), buf[:, :Nk, C:2 * C].float(), buf[:, :Nk, 2 * C:].float())
+    qh, kh, vh = (t.reshape(n, -1, heads, 64).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax((qh.double() @ kh.double().transpose(-1, -2)) * 0.125, -1) @ vh.double()).transpose(1, 2).reshape(n, Nq, C).float()
+    B = buf.to(U.dev())
+    O = torch.full((n, Nq, C), 7.0, dtype=torch.float16, device=U.dev())
+    e = B.element_size()
+    rc = lib.ladi_op_attention(B.data_ptr(), B.data_ptr() + C * e, B.data_ptr() + 2 * C * e, ptr(O), 3 * C, 3 * C, 3 * C, C, T * 3 * C, T * 3 * C, T * 3 * C,
+                               Nq * C, n, heads, Nq, Nk, 0.125, stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    out = O.float().cpu()
+    assert torch.isfinite(out).all()
+    assert U.rel_l2(out, ref) < 3e-3, U.rel_l2(out, ref)
+
+
 # --------------------------------------------------------------------------------------------------------------- refinement UNet helpers
 def test_maxpool2_and_bilinear_upsample(lib):
     """nn.MaxPool2d(2) and nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) on NHWC fp16 (unet_parts.py:33-36,48)"""
