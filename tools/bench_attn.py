@@ -30,6 +30,8 @@ def main():
     print("flash_attn64 (n=%d)" % n)
     for name, heads, Nq, Nk in (("self L0", 5, 3072, 3072), ("self L1", 10, 768, 768), ("self L2", 20, 192, 192), ("cross L0", 5, 3072, 77),
                                 ("cross L1", 10, 768, 77), ("cross L2", 20, 192, 77)):
+        if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] != name.replace(" ", "_"):
+            continue
         C = heads * 64
         q = torch.randn((n, Nq, C), dtype=torch.float16, device=dev)
         k = torch.randn((n, Nk, C), dtype=torch.float16, device=dev)
@@ -37,6 +39,8 @@ def main():
         o = torch.empty_like(q)
         ms = timeit(lambda: lib.ladi_op_attention(ptr(q), ptr(k), ptr(v), ptr(o), C, C, C, C, Nq * C, Nk * C, Nk * C, Nq * C, n, heads, Nq, Nk, 0.125, stream_ptr()))
         print("  %-10s %8.3f ms  %7.1f TF/s" % (name, ms, 4.0 * n * heads * Nq * Nk * 64 / ms / 1e9))
+    if "--attn-only" in sys.argv:
+        return
     print("group_norm (stats+apply, silu)")
     for name, HW, C in (("L0 320", 3072, 320), ("L0 960", 3072, 960), ("L1 640", 768, 640), ("L2 1280", 192, 1280), ("L2 2560", 192, 2560),
                         ("vae 128@512x384 n=2", 196608, 128), ("vae 512@128x96 n=2", 12288, 512)):

@@ -30,7 +30,15 @@ timeout 300 python $R/tools/bench_vae.py > $O/r03_vae_stages.txt 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/ktv -- python $R/tools/bench_vae.py --iters 1 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fv -- python $R/tools/bench_vae.py --iters 1 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_wv -- python $R/tools/bench_vae.py --iters 1 > /dev/null 2>&1
+# attention / norm micro-benchmark: rates, then three counter passes (instruction mix, LDS, MFMA busy) on the 3072-token self-attention alone
+timeout 300 python $R/tools/bench_attn.py > $O/r03_attn_bench.txt 2>/dev/null
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --pmc $set --kernel-trace -d $O/pa$i -- python $R/tools/bench_attn.py --attn-only --only self_L0 > /dev/null 2>&1
+done
 cd $R
+for i in 1 2 3; do python tools/rocpd_pmc.py $(find $O/pa$i -name "*.db" | head -1) $O/r03_attn_pmc_$i.txt --digest $DIG > /dev/null; rm -rf $O/pa$i; done
 python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) $O/r03_unet_forward_kernel_stats.txt > /dev/null
 python tools/rocpd_stats.py $(find $O/ktb -name "*.db" | head -1) $O/r03_bench_kernel_stats.txt > /dev/null
 python tools/rocpd_pmc.py $(find $O/pmc_f -name "*.db" | head -1) $O/r03_pmc_fetch_size.txt --digest $DIG > /dev/null
