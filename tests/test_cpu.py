@@ -293,6 +293,24 @@ def test_igemm_tile_table_names_every_configuration(lib):
     assert not lib.ladi_igemm_cfg_symbol_name(0) and not lib.ladi_igemm_cfg_symbol_name(n + 1)   # out of range: empty, not a crash
 
 
+def test_bench_d2h_pil_tail_encodes_every_image():
+    """the `with_d2h_pil_images_per_s` leg of bench.py: one JPEG (quality 95) per sample of the uint8 batch, as inference.py:314-324 saves them;
+    the byte count it returns is the sum over the batch and the images decode back to the input size"""
+    import io
+    import bench
+    from PIL import Image
+    g = torch.Generator().manual_seed(3)
+    batch = (torch.rand((3, 64, 48, 3), generator=g) * 255).to(torch.uint8)
+    n = bench.d2h_pil_tail(batch)
+    sizes = []
+    for im in batch.numpy():
+        buf = io.BytesIO()
+        Image.fromarray(im).save(buf, format="JPEG", quality=95)
+        sizes.append(buf.tell())
+        assert Image.open(io.BytesIO(buf.getvalue())).size == (48, 64)
+    assert n == sum(sizes) and all(s > 0 for s in sizes)
+
+
 def test_native_host_scheduler_tables_match_oracle(lib):
     buf = (ctypes.c_int * 1100)()
     for kind in (0, 1):
