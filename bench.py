@@ -82,6 +82,9 @@ def parse():
                         "summaries under profiles/ are taken from)")
     p.add_argument("--roofline-iters", type=int, default=4)
     p.add_argument("--no-tail", action="store_true", help="skip the D2H + PIL leg (with_d2h_pil_images_per_s)")
+    p.add_argument("--lanes", type=int, default=None,
+                   help="sample-group lanes of the UNet forward inside the denoising loop (csrc/runtime.h UNetLanes); default: the library's "
+                        "own choice (LADI_UNET_LANES, else 2)")
     return p.parse_args()
 
 
@@ -178,13 +181,88 @@ def traffic_measured(symbol, extra_args):
             "launches": vals["FETCH_SIZE"][1], "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled)"}, None
 
 
+PROFILE_ROUND = "r04"      # the committed rocprofv3 summaries this line may cite (profiles/<round>_*), digest-checked
+
+
+def _pmc_file(prefix, tag):
+    """{symbol line -> (avg KiB per dispatch, avg us under the PMC pass)} of profiles/<round>_<prefix>pmc_<tag>_size.txt, or (None, why)"""
+    path = os.path.join(ROOT, "profiles", "%s_%spmc_%s_size.txt" % (PROFILE_ROUND, prefix, tag))
+    if not os.path.exists(path):
+        return None, "no committed PMC pass (%s)" % os.path.relpath(path, ROOT)
+    lines = open(path).read().splitlines()
+    m = re.match(r"# lib_digest=(\w+)", lines[0]) if lines else None
+    if not m or m.group(1) != lib_digest():
+        return None, "committed PMC passes are stale (taken with another library build); re-run tools/make_profiles.sh"
+    out = {}
+    for line in lines[2:]:
+        f = line.split()
+        if len(f) >= 6:
+            out[line] = (float(f[-2]), float(f[-1]))
+    return out, None
+
+
+def _stats_file(prefix):
+    """{symbol line -> (calls, avg us)} of profiles/<round>_<prefix>kernel_stats.txt (rocprofv3 --kernel-trace --stats of the same command)"""
+    path = os.path.join(ROOT, "profiles", "%s_%skernel_stats.txt" % (PROFILE_ROUND, prefix))
+    if not os.path.exists(path):
+        return None
+    out = {}
+    for line in open(path).read().splitlines()[1:]:
+        f = line.split()
+        if len(f) >= 7 and not line.startswith("TOTAL"):
+            try:
+                out[line] = (int(f[-6]), float(f[-4]))
+            except ValueError:
+                pass
+    return out
+
+
+HBM_KERNELS = ("gn_apply_kernel", "gn_finalize_kernel", "gn_partial_kernel", "splitk_reduce_kernel", "layernorm_kernel", "sched_step_kernel",
+               "image_post_kernel", "assemble_static_kernel")
+
+
+def hbm_kernels():
+    """north_star "achieved HBM GB/s": for the HBM-bound kernels of the path (normalisation, split-K reduce, scheduler step) and the
+    convolutions of the VAE stages, bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE of the committed, digest-checked PMC passes (FETCH
+    doubled: gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md) divided by the kernel's average duration in the committed
+    rocprofv3 kernel trace of the same command.  profiles/README.md shows the recomputation."""
+    res = {}
+    for prefix, leg, pick in (("", "unet_forward", lambda n: any(k in n for k in HBM_KERNELS)),
+                              ("vae_", "vae_stages", lambda n: True)):
+        fe, why = _pmc_file(prefix, "fetch")
+        wr, why2 = _pmc_file(prefix, "write")
+        st = _stats_file(prefix if prefix else "unet_forward_")
+        if fe is None or wr is None or st is None:
+            res[leg] = {"note": why or why2 or "no committed kernel trace"}
+            continue
+
+        def key(line):
+            return re.split(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+", line)[0].strip()
+        fk = {key(l): v for l, v in fe.items()}
+        wk = {key(l): v for l, v in wr.items()}
+        rows = {}
+        for line, (calls, us) in st.items():
+            name = re.split(r"\s{2,}", line.strip())[0]
+            if not pick(name):
+                continue
+            k78 = name[:78]
+            if k78 in fk and k78 in wk and us > 0:
+                b = 2.0 * fk[k78][0] * 1024.0 + wk[k78][0] * 1024.0
+                short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name).split("E", 1)[0] if name.startswith("_ZN") else name.replace("void ", "")
+                rows[short[:60]] = {"GBps": round(b / us / 1e3, 1), "frac_of_8TBps": round(b / us / 1e3 / 8000.0, 3), "avg_us": us,
+                                    "MB_per_launch": round(b / 1e6, 2), "launches": calls}
+        res[leg] = dict(sorted(rows.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"])[:10])
+    res["source"] = "profiles/%s_{,vae_}pmc_{fetch,write}_size.txt + %s_{unet_forward,vae}_kernel_stats.txt (same library digest)" % (PROFILE_ROUND, PROFILE_ROUND)
+    return res
+
+
 def traffic_committed(symbol):
-    """profiles/r03_pmc_{fetch,write}_size.txt, valid only for the library build they were taken with (first line: # lib_digest=...)"""
+    """profiles/<round>_pmc_{fetch,write}_size.txt, valid only for the library build they were taken with (first line: # lib_digest=...)"""
     vals = {}
     for tag in ("fetch", "write"):
-        path = os.path.join(ROOT, "profiles", "r03_pmc_%s_size.txt" % tag)
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s_size.txt" % (PROFILE_ROUND, tag))
         if not os.path.exists(path):
-            return None, "no committed PMC pass (profiles/r03_pmc_%s_size.txt)" % tag
+            return None, "no committed PMC pass (profiles/%s_pmc_%s_size.txt)" % (PROFILE_ROUND, tag)
         lines = open(path).read().splitlines()
         m = re.match(r"# lib_digest=(\w+)", lines[0]) if lines else None
         if not m or m.group(1) != lib_digest():
@@ -196,8 +274,8 @@ def traffic_committed(symbol):
     if len(vals) != 2:
         return None, "kernel %s not in the committed PMC passes" % symbol
     return {"bytes_per_launch": round(2.0 * vals["fetch"] + vals["write"]), "fetch_bytes_x2": round(2.0 * vals["fetch"]),
-            "write_bytes": round(vals["write"]), "source": "profiles/r03_pmc_{fetch,write}_size.txt (same library digest; avg over all launches "
-            "of this kernel in `bench.py --roofline-only`)"}, None
+            "write_bytes": round(vals["write"]), "source": "profiles/%s_pmc_{fetch,write}_size.txt (same library digest; avg over all launches "
+            "of this kernel in `bench.py --roofline-only`)" % PROFILE_ROUND}, None
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -329,19 +407,18 @@ def main():
     global_B = B * world
     lo = rank * B
     local = make_rows(lo, lo + B, H, W, Ltok, D, dev)      # this rank's rows of the global batch, resident in HBM before the timed region
-    clip_mean = torch.tensor([0.48145466, 0.4578275, 0.40821073], device=dev).view(1, 3, 1, 1)
-    clip_std = torch.tensor([0.26862954, 0.26130258, 0.27577711], device=dev).view(1, 3, 1, 1)
+    if a.lanes is not None:
+        pipe.lanes = a.lanes
 
     def run_local(inp):
         pe = inp["prompt_embeds"]
         if producers:   # src/inference.py:267-295: in-shop cloth -> CLIP ViT-H/14 -> inversion adapter -> pseudo-word splice -> CLIP text encoder
-            img224 = L.resize_antialias((inp["cloth"].float() + 1) / 2, (224, 224)).clamp(0, 1)
-            feats = vision(((img224 - clip_mean) / clip_std).half()).last_hidden_state
+            feats = vision(L.clip_preprocess(inp["cloth"])).last_hidden_state     # resize + clamp + CLIP normalisation: one kernel
             words = adapter(feats).reshape(feats.shape[0], 16, -1)
             pe = L.encode_text_word_embedding(text, inp["word_ids"], words, 16).last_hidden_state
         return pipe._run_fused(inp["image"], inp["mask_image"], inp["pose_map"], inp["warped_cloth"], pe, inp["negative_prompt_embeds"],
                                inp["noise_cloth"], inp["noise_latents"], inp["noise_masked"], H, W, steps_inf, 7.5, 1.0, False, not a.no_graph,
-                               return_device=True)
+                               return_device=True, out_uint8=True)     # uint8 straight from the decode epilogue (numpy_to_pil rounding)
 
     one_step = make_step(run_local, local, lo, B, global_B)   # contiguous row shards + the path's only collective (RCCL all-gather of uint8 images)
 
@@ -402,6 +479,26 @@ def main():
         n = 2 * B
         h, w = H // 8, W // 8
         whole_ms = unet.time_forward(n, h, w, a.roofline_iters)
+        # the forward the way the denoising loop runs it (sample-group lanes on parallel streams inside one hipGraph), with the shader clock
+        # read next to it by a one-wave probe on a side stream (DVFS: every "fraction of peak" here is against the NOMINAL 2.4 GHz)
+        lanes_ms, lanes_n, clock = None, None, None
+        try:
+            probe = torch.zeros(2, dtype=torch.int64, device=dev)
+            side = torch.cuda.Stream()
+            lanes_n = int(a.lanes) if a.lanes else int(os.environ.get("LADI_UNET_LANES", "2"))
+            while lanes_n > 1 and n % lanes_n:
+                lanes_n -= 1
+            unet.time_forward_lanes(n, h, w, 1, lanes_n)                      # builds / tunes
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                lib.ladi_clock_probe(ctypes.c_ulonglong(int(whole_ms * 1e5 * 6)), ctypes.c_void_p(probe.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+            lanes_ms = unet.time_forward_lanes(n, h, w, max(a.roofline_iters, 8), lanes_n)
+            torch.cuda.synchronize()
+            cyc, ticks = [int(v) for v in probe.cpu()]
+            clock = {"under_unet_forward_mhz": round(cyc / max(ticks, 1) * 100.0, 1), "nominal_mhz": 2400.0,
+                     "how": "one-wave probe on a side stream (s_memtime / s_memrealtime over %.1f ms) while the forwards run" % (ticks / 1e5)}
+        except Exception as e:   # reported, never required
+            clock = {"error": repr(e)}
         lib.ladi_profile_igemm_enable(1)
         unet.time_forward(n, h, w, a.roofline_iters)   # 1 warm-up + roofline_iters timed forwards, all recorded
         lib.ladi_profile_igemm_enable(0)
@@ -442,6 +539,10 @@ def main():
                                            "total_ms": round(v["ms"], 3)} for k, v in sorted(sym.items(), key=lambda kv: -kv[1]["ms"])},
                         "unet_forward_ms": round(whole_ms, 3),
                         "unet_forward_tflops": round(fwd_flop / whole_ms / 1e9, 2) if fwd_flop else None,
+                        "unet_forward_lanes": lanes_n, "unet_forward_lanes_ms": round(lanes_ms, 3) if lanes_ms else None,
+                        "unet_forward_lanes_tflops": round(fwd_flop / lanes_ms / 1e9, 2) if (fwd_flop and lanes_ms) else None,
+                        "clock": clock, "hbm_kernels": hbm_kernels() if default_workload else None,
+                        "splitk_reduce": "charged to the symbol of the kernel that needed it (HIP events close after the reduce pass)",
                         "whole_path_frac": round(images_per_s / world * flop_img / 1e12 / PEAK_F16_TFLOPS, 4) if flop_img and a.steps else None}
     cpu = None
     if want_cpu:
@@ -458,7 +559,7 @@ def main():
                                    "checkpoint" % (cfg["name"], steps_inf, scheduler.upper(), evals, H, W, a.size),
                        "baseline_config_index": a.config, "batch_per_gpu": B, "global_batch": global_B, "producers_in_step": bool(producers),
                        "parallelism": "dp%d (contiguous row shards of the global batch + RCCL all-gather of uint8 images)" % world,
-                       "hipgraph": not a.no_graph},
+                       "hipgraph": not a.no_graph, "unet_lanes": (lib.ladi_tryon_lanes(pipe._tryon) if pipe._tryon else None)},
             "stage_ms_rank0": stage_ms, "model_build_s": round(t_build, 1),
             "with_d2h_pil_images_per_s": tail["images_per_s"] if tail else None, "d2h_pil_tail": tail,
             "roofline": roofline, "cpu_baseline": cpu,

@@ -232,15 +232,28 @@ ladi_tryon* ladi_tryon_create(ladi_unet* unet, ladi_vae* vae, ladi_emasc* emasc)
 void ladi_tryon_destroy(ladi_tryon* t);
 /* images_dev: fp32 [B,H,W,3] in [0,1] (decode_latents layout, tryon_pipe.py:356-358); latents_dev: optional fp32 [B,4,h,w] */
 int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images_dev, float* latents_dev, void* stream);
+/* the same call with the batch in the dtype numpy_to_pil produces (tryon_pipe.py:357-360): uint8 [B,H,W,3] = round(image * 255),
+ * round-half-to-even like numpy -- what the RCCL all-gather of the sharded path and the JPEG encoder consume */
+int ladi_tryon_run_u8(ladi_tryon* t, const ladi_tryon_inputs* in, unsigned char* images_dev, float* latents_dev, void* stream);
 /* per-evaluation trace for parity tests (tryon_pipe.py:732-740 intermediate values): subsequent runs write the guided noise prediction
  * and the updated latents of evaluation i to *_trace_dev[i] (fp32 [B, h*w, 4] each) for i < cap_evals; NULL pointers switch it off.
  * Buffers are caller-owned and must outlive the runs. */
 int ladi_tryon_set_trace(ladi_tryon* t, float* eps_trace_dev, float* latents_trace_dev, int cap_evals);
 /* stage times (ms) of the last run: [0] preprocess + VAE encodes + EMASC, [1] denoising loop, [2] decode. Sync first. */
 int ladi_tryon_stage_ms(ladi_tryon* t, float* out3);
+/* sample-group lanes of the denoising loop: the UNet forward of the 2B (CFG) or B samples runs as `lanes` independent forwards on as
+ * many HIP streams inside one hipGraph (csrc/runtime.h UNetLanes).  0 = default (environment LADI_UNET_LANES, else 2); a count that
+ * does not divide the sample count falls back to the default rule.  Results do not depend on it beyond fp16 rounding of other tile
+ * selections.  ladi_tryon_lanes() returns the count the last run used. */
+int ladi_tryon_set_lanes(ladi_tryon* t, int lanes);
+int ladi_tryon_lanes(ladi_tryon* t);
 /* run ONLY `iters` UNet forwards (n samples of h x w latents, context already set) bracketed by HIP events on `stream`
  * and return the average milliseconds per forward (synchronises). Used by bench.py for the roofline figure. */
 int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* avg_ms, void* stream);
+/* the same measurement of the forward as the denoising loop runs it: `lanes` independent sample groups on as many HIP streams (0 =
+ * the loop's own choice, LADI_UNET_LANES or 2; must divide n), replayed from one hipGraph with `lanes` parallel branches when
+ * use_graph != 0.  Runs on an internal stream fenced against `stream`; synchronises. */
+int ladi_unet_time_forward_lanes(ladi_unet* u, int n, int h, int w, int iters, int lanes, int use_graph, float* avg_ms, void* stream);
 
 /* per-launch HIP-event timing of the implicit-GEMM kernel family (the dominant kernel): enable, run any entry point,
  * then collect: out[cfg*3 + {0,1,2}] = {total ms, algorithmic FLOP = 2*P*Q*K, launches} for tile configuration cfg = 1..ladi_igemm_cfg_count()
@@ -296,6 +309,14 @@ int ladi_op_resize_bilinear_aa(const void* src, int dtype, int planes, int H, in
 /* F.grid_sample(x [B,C,H,W], grid fp32 [B,Ho,Wo,2], mode bilinear, padding_mode "border", align_corners False) -> [B,C,Ho,Wo] */
 int ladi_op_grid_sample_border(const void* src, int dtype, int B, int C, int H, int W, const float* grid, int Ho, int Wo, void* dst,
                                int out_dtype, void* stream);
+/* shader-clock probe for the bench's roofline bookkeeping: one wave spins for `wall_ticks_100mhz` ticks of the constant 100 MHz counter
+ * (at most 10^8 = 1 s) on `stream` -- a side stream, next to the work being measured -- and writes {shader cycles, wall ticks} to
+ * out2_dev (2 x uint64, device): cycles / ticks * 100 = the MHz the chip sustained under that load */
+int ladi_clock_probe(unsigned long long wall_ticks_100mhz, unsigned long long* out2_dev, void* stream);
+/* CLIP image pre-processing of the in-shop cloth in one pass (src/inference.py:268-272): resize((x + 1) / 2, (size, size), antialias)
+ * .clamp(0, 1), then (v - mean[c]) / std[c]; src [B,3,H,W] in [-1,1] (dtype 0 fp32 / 1 fp16), dst fp16 [B,3,size,size]; mean3 / std3 host */
+int ladi_op_clip_preprocess(const void* src, int dtype, int B, int H, int W, int size, const float* mean3, const float* std3, void* dst_f16,
+                            void* stream);
 /* NHWC fp16 helpers of the refinement UNet: 2x2 max pooling, bilinear x2 upsampling with align_corners=True (C % 8 == 0) */
 int ladi_op_maxpool2(const void* src, int n, int H, int W, int C, void* dst, void* stream);
 int ladi_op_upsample2x_bilinear(const void* src, int n, int H, int W, int C, void* dst, void* stream);

@@ -11,7 +11,7 @@ from .pipeline import StableDiffusionTryOnePipeline  # noqa: F401
 from .schedulers import DDIMScheduler, LMSDiscreteScheduler, PNDMScheduler  # noqa: F401
 from .text import NativeCLIPTextEncoder, encode_text_word_embedding  # noqa: F401
 from .vision import NativeCLIPVisionEncoder  # noqa: F401
-from .warp import NativeRefinementUNet, NativeTPS, grid_sample_border, resize_antialias, warp_cloth  # noqa: F401
+from .warp import NativeRefinementUNet, NativeTPS, clip_preprocess, grid_sample_border, resize_antialias, warp_cloth  # noqa: F401
 
 
 def build_random_init_pipeline(size="full", scheduler="ddim", with_emasc=True):

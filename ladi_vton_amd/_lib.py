@@ -95,6 +95,7 @@ SIGNATURES = {
     "ladi_unet_set_context": (c_int, [_P, _P, c_int, c_int, _P]),
     "ladi_unet_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int, _P]),
     "ladi_unet_time_forward": (c_int, [_P, c_int, c_int, c_int, c_int, POINTER(c_float), _P]),
+    "ladi_unet_time_forward_lanes": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), _P]),
     "ladi_vae_create": (_P, [POINTER(VAEConfig), _P]),
     "ladi_vae_destroy": (None, [_P]),
     "ladi_vae_encode": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, POINTER(_P), _P]),
@@ -124,8 +125,11 @@ SIGNATURES = {
     "ladi_tryon_create": (_P, [_P, _P, _P]),
     "ladi_tryon_destroy": (None, [_P]),
     "ladi_tryon_run": (c_int, [_P, POINTER(TryOnInputs), _P, _P, _P]),
+    "ladi_tryon_run_u8": (c_int, [_P, POINTER(TryOnInputs), _P, _P, _P]),
     "ladi_tryon_stage_ms": (c_int, [_P, POINTER(c_float)]),
     "ladi_tryon_set_trace": (c_int, [_P, _P, _P, c_int]),
+    "ladi_tryon_set_lanes": (c_int, [_P, c_int]),
+    "ladi_tryon_lanes": (c_int, [_P]),
     "ladi_vae_set_range_shift": (c_int, [_P, c_int]),
     "ladi_vae_last_range_shift": (c_int, [_P]),
     "ladi_igemm_set_autotune": (None, [c_int]),
@@ -146,6 +150,8 @@ SIGNATURES = {
     "ladi_op_attention_wide": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,
                                        c_int, c_int, c_int, c_int, c_float, _P]),
     "ladi_op_resize_bilinear_aa": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
+    "ladi_clock_probe": (c_int, [ctypes.c_ulonglong, _P, _P]),
+    "ladi_op_clip_preprocess": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), _P, _P]),
     "ladi_op_grid_sample_border": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, _P]),
     "ladi_op_maxpool2": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "ladi_op_upsample2x_bilinear": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),

@@ -10,7 +10,7 @@ using namespace ladi;
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct ladi_weights { WeightStore ws; };
-struct ladi_unet { UNet u; };
+struct ladi_unet { UNet u; UNetLanes lanes; Arena io; };
 struct ladi_vae { VAE v; };
 struct ladi_emasc { EMASC e; };
 struct ladi_adapter { Adapter a; };
@@ -150,6 +150,65 @@ int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* 
         HIP_OK(hipEventElapsedTime(&ms, e0, e1));
         *avg_ms = ms / (float)iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        return 0;
+    });
+}
+
+int ladi_unet_time_forward_lanes(ladi_unet* u, int n, int h, int w, int iters, int lanes, int use_graph, float* avg_ms, void* stream) {
+    return guarded("ladi_unet_time_forward_lanes", [&]() {
+        UNet& U = u->u;
+        UNetLanes& LN = u->lanes;
+        if (iters < 1 || n < 1) throw std::runtime_error("bad arguments");
+        hipStream_t user = S(stream), st = nullptr;
+        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));      // the NULL stream cannot be captured
+        hipEvent_t e0 = nullptr, e1 = nullptr, ein = nullptr;
+        hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+        auto cleanup = [&]() {
+            if (gexec) (void)hipGraphExecDestroy(gexec);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (ein) (void)hipEventDestroy(ein);
+            (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st);
+        };
+        try {
+            HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreateWithFlags(&ein, hipEventDisableTiming));
+            HIP_OK(hipEventRecord(ein, user)); HIP_OK(hipStreamWaitEvent(st, ein, 0));
+            float t0 = 500.f;
+            if (U.compute_temb(&t0, 1, st)) return -1;
+            LN.configure(n, lanes > 0 ? lanes : 0);
+            const int eps_ld = (U.cfg.out_channels + 3) / 4 * 4;
+            Arena& io = u->io;
+            Act x, eps;
+            for (int pass = 0; pass < 2; ++pass) {
+                io.dry = (pass == 0); io.off = 0;
+                Ctx c; c.st = st; c.ar = &io;
+                x = c.new_act(n, h, w, 64);
+                eps = c.new_act(n, h, w, U.cfg.out_channels, eps_ld);
+                if (pass == 0) { LN.forward(U, st, true, false, x, eps, U.temb_table, nullptr); LN.commit_plan(); io.reserve(io.peak + 4096); }
+            }
+            HIP_OK(hipMemsetAsync(x.p, 0, x.pixels() * 64 * sizeof(h16), st));
+            LN.forward(U, st, false, false, x, eps, U.temb_table, nullptr);      // warm-up, lanes in sequence (tile measurement)
+            if (use_graph) {
+                HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+                try { LN.forward(U, st, false, true, x, eps, U.temb_table, nullptr); }
+                catch (...) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); throw; }
+                HIP_OK(hipStreamEndCapture(st, &graph));
+                HIP_OK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+                HIP_OK(hipGraphLaunch(gexec, st));                              // one untimed replay
+            } else LN.forward(U, st, false, true, x, eps, U.temb_table, nullptr);
+            HIP_OK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) {
+                if (use_graph) HIP_OK(hipGraphLaunch(gexec, st));
+                else LN.forward(U, st, false, true, x, eps, U.temb_table, nullptr);
+            }
+            HIP_OK(hipEventRecord(e1, st));
+            HIP_OK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+            *avg_ms = ms / (float)iters;
+        } catch (...) { cleanup(); throw; }
+        cleanup();
         return 0;
     });
 }
@@ -466,8 +525,8 @@ ladi_tryon* ladi_tryon_create(ladi_unet* unet, ladi_vae* vae, ladi_emasc* emasc)
     return t;
 }
 void ladi_tryon_destroy(ladi_tryon* t) { delete t; }
-int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images, float* latents, void* stream) {
-    return guarded("ladi_tryon_run", [&]() {
+static int tryon_run_any(ladi_tryon* t, const ladi_tryon_inputs* in, void* images, int images_u8, float* latents, void* stream) {
+    return guarded(images_u8 ? "ladi_tryon_run_u8" : "ladi_tryon_run", [&]() {
         if (!t || !in || !images) throw std::runtime_error("null argument");
         TryOnInputs ti;
         ti.batch = in->batch; ti.height = in->height; ti.width = in->width; ti.in_f32 = in->in_dtype == LADI_F32;
@@ -483,10 +542,22 @@ int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images, fl
         if (ti.steps < 2 || ti.steps > 1000) throw std::runtime_error("num_inference_steps out of range");
         if (!ti.image || !ti.mask_image || !ti.pose_map || !ti.prompt_embeds || !ti.noise_latents || !ti.noise_masked) throw std::runtime_error("missing input");
         if (ti.warped_cloth && !ti.noise_cloth) throw std::runtime_error("noise_cloth required with warped_cloth");
-        return t->t.run(ti, images, latents, S(stream));
+        return t->t.run(ti, images, images_u8, latents, S(stream));
     });
 }
+int ladi_tryon_run(ladi_tryon* t, const ladi_tryon_inputs* in, float* images, float* latents, void* stream) {
+    return tryon_run_any(t, in, images, 0, latents, stream);
+}
+int ladi_tryon_run_u8(ladi_tryon* t, const ladi_tryon_inputs* in, unsigned char* images, float* latents, void* stream) {
+    return tryon_run_any(t, in, images, 1, latents, stream);
+}
 int ladi_tryon_stage_ms(ladi_tryon* t, float* out3) { return t ? t->t.stage_ms(out3) : -1; }
+int ladi_tryon_set_lanes(ladi_tryon* t, int lanes) {
+    if (!t || lanes < 0 || lanes > UNetLanes::MAXG) { set_error("ladi_tryon_set_lanes: lanes must be in [0, 8]"); return -1; }
+    t->t.lanes_override = lanes;
+    return 0;
+}
+int ladi_tryon_lanes(ladi_tryon* t) { return t ? t->t.lanes.G : -1; }
 int ladi_tryon_set_trace(ladi_tryon* t, float* eps_trace, float* latents_trace, int cap_evals) {
     if (!t || cap_evals < 0) return -1;
     t->t.trace_eps = eps_trace; t->t.trace_lat = latents_trace; t->t.trace_cap = (eps_trace || latents_trace) ? cap_evals : 0;
@@ -570,6 +641,17 @@ int ladi_op_attention_wide(const void* q, const void* k, const void* vt, void* o
 int ladi_op_resize_bilinear_aa(const void* src, int dtype, int planes, int H, int W, void* dst, int out_dtype, int Ho, int Wo, void* stream) {
     return ladi_launch_resize_bilinear_aa(src, dtype == LADI_F32, planes, H, W, dst, out_dtype == LADI_F32, Ho, Wo, S(stream));
 }
+int ladi_clock_probe(unsigned long long wall_ticks_100mhz, unsigned long long* out2_dev, void* stream) {
+    if (!out2_dev || wall_ticks_100mhz == 0 || wall_ticks_100mhz > 100000000ull) return -1;      // at most one second
+    return ladi_launch_clock_probe(wall_ticks_100mhz, out2_dev, S(stream));
+}
+int ladi_op_clip_preprocess(const void* src, int dtype, int B, int H, int W, int size, const float* mean3, const float* std3, void* dst_f16, void* stream) {
+    if (!src || !dst_f16 || !mean3 || !std3 || B <= 0 || size <= 0) return -1;
+    ResizeEpi e; e.on = 1; e.C = 3; e.pre_mul = 0.5f; e.pre_add = 0.5f;
+    for (int i = 0; i < 3; ++i) { e.sub[i] = mean3[i]; e.div[i] = std3[i]; }
+    e.sub[3] = 0.f; e.div[3] = 1.f;
+    return ladi_launch_resize_bilinear_aa(src, dtype == LADI_F32, B * 3, H, W, dst_f16, 0, size, size, S(stream), &e);
+}
 int ladi_op_grid_sample_border(const void* src, int dtype, int B, int C, int H, int W, const float* grid, int Ho, int Wo, void* dst,
                                int out_dtype, void* stream) {
     return ladi_launch_grid_sample_border(src, dtype == LADI_F32, B, C, H, W, grid, Ho, Wo, dst, out_dtype == LADI_F32, S(stream));
@@ -631,7 +713,7 @@ int ladi_op_sched_run(int kind, int steps, const float* ac_host, const void* eps
         float* cur = reinterpret_cast<float*>(buf + tb_bytes + 256);
         float* ets = cur + (size_t)B * hw * 4;
         HIP_OK(hipMemcpyAsync(dt, tb.data(), tb.size() * sizeof(StepTable), hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemsetAsync(dstep, 0, 4, st));
+        HIP_OK(hipMemsetAsync(dstep, 0, 8, st));       // evaluation index + the step kernel's arrival ticket
         const int rows = (cfg ? 2 : 1) * B * hw;
         int rc = 0;
         for (int i = 0; i < evals && !rc; ++i) {

@@ -124,11 +124,7 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, int count
 // ------------------------------------------------------------------------------------------------
 // fused CFG combine + scheduler update (DDIM or PLMS table entry) + UNet-input refresh
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sched_step_kernel(const StepArgs a) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;  // (b, pixel)
-    const int total = a.B * a.hw;
-    if (idx >= total) return;
-    const int step = *a.step_idx;
+__device__ __forceinline__ void sched_step_body(const StepArgs& a, const int idx, const int total, const int step) {
     const StepTable T = a.table[step];
     const int b = idx / a.hw;
     const size_t row_u = (size_t)idx;                       // uncond (or only) row
@@ -184,7 +180,19 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const StepArgs a) {
         }
     }
 }
-__global__ void bump_counter_kernel(int* p) { *p = *p + 1; }
+// Every block reads the evaluation index first; the LAST block to finish (arrival ticket at step_idx[1]) advances it for the next
+// evaluation and re-arms the ticket: the counter needs no launch of its own and cannot change under a block that has not read it yet.
+__global__ __launch_bounds__(256) void sched_step_kernel(const StepArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // (b, pixel)
+    const int total = a.B * a.hw;
+    const int step = *a.step_idx;
+    if (idx < total) sched_step_body(a, idx, total, step);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(a.step_idx + 1, 1) == (int)gridDim.x - 1) { a.step_idx[1] = 0; a.step_idx[0] = step + 1; }
+    }
+}
 
 __global__ __launch_bounds__(256) void assemble_static_kernel(h16* __restrict__ unet_in, int ld_in, int B, int hw, int cfg,
                                                               const float* __restrict__ latents,
@@ -264,12 +272,20 @@ __global__ void pose_down8_kernel(const PT* __restrict__ pose, int B, int C, int
     dst[idx] = (h16)v;
 }
 
-__global__ void image_post_kernel(const h16* __restrict__ src, int ld, int n_pix, float* __restrict__ dst) {
+// decode_latents' tail (tryon_pipe.py:356-358): (image / 2 + 0.5).clamp(0, 1), channels last.  U8: followed by numpy_to_pil's rounding
+// (tryon_pipe.py:357-360 `(images * 255).round().astype("uint8")`, round-half-to-even like numpy) so that the batch leaves the library
+// in the dtype the all-gather and the JPEG encoder want
+template <bool U8>
+__global__ void image_post_kernel(const h16* __restrict__ src, int ld, int n_pix, void* __restrict__ dst) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_pix) return;
     const h16* s = src + (size_t)idx * ld;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dst[(size_t)idx * 3 + c] = fminf(fmaxf((float)s[c] * 0.5f + 0.5f, 0.f), 1.f);
+    for (int c = 0; c < 3; ++c) {
+        const float v = fminf(fmaxf((float)s[c] * 0.5f + 0.5f, 0.f), 1.f);
+        if constexpr (U8) reinterpret_cast<unsigned char*>(dst)[(size_t)idx * 3 + c] = (unsigned char)rintf(v * 255.0f);
+        else reinterpret_cast<float*>(dst)[(size_t)idx * 3 + c] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void mask_mul_kernel(h16* __restrict__ feat, int C, int n_pix, const h16* __restrict__ mask) {
@@ -364,7 +380,6 @@ int ladi_launch_timestep_embedding(const float* t, int count, int dim, float* ou
 int ladi_launch_sched_step(const StepArgs& a, hipStream_t st) {
     const int total = a.B * a.hw;
     hipLaunchKernelGGL(sched_step_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, a.step_idx);
     return ok();
 }
 
@@ -419,8 +434,9 @@ int ladi_launch_pose_down8(const void* pose_nchw, int f32, int B, int C, int H, 
     return ok();
 }
 
-int ladi_launch_image_post(const h16* src, int ld, int n_pix, float* dst, hipStream_t st) {
-    hipLaunchKernelGGL(image_post_kernel, dim3((n_pix + 255) / 256), dim3(256), 0, st, src, ld, n_pix, dst);
+int ladi_launch_image_post(const h16* src, int ld, int n_pix, void* dst, int dst_u8, hipStream_t st) {
+    if (dst_u8) hipLaunchKernelGGL(image_post_kernel<true>, dim3((n_pix + 255) / 256), dim3(256), 0, st, src, ld, n_pix, dst);
+    else hipLaunchKernelGGL(image_post_kernel<false>, dim3((n_pix + 255) / 256), dim3(256), 0, st, src, ld, n_pix, dst);
     return ok();
 }
 
@@ -666,8 +682,10 @@ __device__ __forceinline__ void st_any(void* p, int f32, size_t i, float v) {
 //   scale = in / out, support = max(scale, 1), centre = scale * (o + 0.5), taps [int(centre - support + 0.5), int(centre + support + 0.5))
 //   clipped to the image, weight = max(0, 1 - |(tap + 0.5 - centre) / max(scale, 1)|), normalised to sum 1.
 // One thread per output element evaluates the 2-D product of the two 1-D filters in fp32 (<= 7 x 7 taps for the 2.3x reductions here).
+// Optional value epilogue `e` (the CLIP image pre-processing of src/inference.py:268-272 in the same pass): v = v * pre_mul + pre_add,
+// clamp to [0, 1], then (v - sub[c]) / div[c] with c = plane % C.
 __global__ __launch_bounds__(256) void resize_bilinear_aa_kernel(const void* __restrict__ src, int in_f32, int planes, int H, int W,
-                                                                 void* __restrict__ dst, int out_f32, int Ho, int Wo) {
+                                                                 void* __restrict__ dst, int out_f32, int Ho, int Wo, const ResizeEpi e) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)planes * Ho * Wo;
     if (idx >= total) return;
@@ -691,7 +709,13 @@ __global__ __launch_bounds__(256) void resize_bilinear_aa_kernel(const void* __r
             row += fmaxf(0.f, 1.f - fabsf(((float)x - cx + 0.5f) * ix)) * ld_any(src, in_f32, base + (size_t)y * W + x);
         acc += wy * row;
     }
-    st_any(dst, out_f32, idx, acc / (wys * wxs));
+    float v = acc / (wys * wxs);
+    if (e.on) {
+        v = fminf(fmaxf(v * e.pre_mul + e.pre_add, 0.f), 1.f);
+        const int c = (int)(pl % (size_t)e.C);
+        v = (v - e.sub[c]) / e.div[c];
+    }
+    st_any(dst, out_f32, idx, v);
 }
 
 // F.grid_sample(x, grid, mode="bilinear", padding_mode="border", align_corners=False) (src/inference.py:260): x = ((g + 1) * size - 1) / 2
@@ -726,11 +750,14 @@ __global__ __launch_bounds__(256) void grid_sample_border_kernel(const void* __r
 }  // namespace
 
 int ladi_launch_resize_bilinear_aa(const void* src, int in_f32, int planes, int H, int W, void* dst, int out_f32, int Ho, int Wo,
-                                   hipStream_t st) {
+                                   hipStream_t st, const ResizeEpi* epi) {
     if (planes <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return -1;
+    ResizeEpi e; e.on = 0; e.C = 1; e.pre_mul = 1.f; e.pre_add = 0.f;
+    for (int i = 0; i < 4; ++i) { e.sub[i] = 0.f; e.div[i] = 1.f; }
+    if (epi) { e = *epi; if (e.C < 1 || e.C > 4) return -1; }
     const size_t total = (size_t)planes * Ho * Wo;
     hipLaunchKernelGGL(resize_bilinear_aa_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, in_f32, planes, H, W, dst,
-                       out_f32, Ho, Wo);
+                       out_f32, Ho, Wo, e);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 
@@ -741,6 +768,21 @@ int ladi_launch_grid_sample_border(const void* src, int in_f32, int B, int C, in
     hipLaunchKernelGGL(grid_sample_border_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, in_f32, B, C, H, W, grid,
                        Ho, Wo, dst, out_f32);
     return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+// Shader-clock probe (bench.py `clock`): ONE wave spins for `wall_ticks` ticks of the constant 100 MHz counter (s_memrealtime) and
+// reports how many shader cycles (s_memtime) went by -- launched on a side stream next to the kernels being measured, it reads the clock
+// the chip actually sustains under that load (DVFS: 2.4 GHz nominal, ~1.9 GHz under dense MFMA work, MI355X_MICROARCH.md).
+__global__ void clock_probe_kernel(unsigned long long wall_ticks, unsigned long long* out) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    unsigned long long w1 = w0;
+    while (w1 - w0 < wall_ticks) { __builtin_amdgcn_s_sleep(32); w1 = wall_clock64(); }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+}
+int ladi_launch_clock_probe(unsigned long long wall_ticks, unsigned long long* out2, hipStream_t st) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, wall_ticks, out2);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // dst = src * s (fp16 NHWC rows of C channels; the VAE range guard's scaled copies of the EMASC skips)

@@ -526,11 +526,13 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     const int batch_l = lbatch;
     int rc;
     rc = launch_base(cfg, a, batch_l, st);
-    if (prof) { (void)hipEventRecord(rec.e1, st); g_recs.push_back(rec); }   // the main kernel only (the reduce pass is its own symbol)
     if (rc == 0 && split > 1) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((full.P + 31) / 32), (unsigned)((full.Q + 63) / 64)), dim3(256), 0, st, ws, split, full);
         if (hipGetLastError() != hipSuccess) rc = -11;
     }
+    // work-complete timing: a split-K launch is not done until its reduce pass has written the output, so the pass is charged to the
+    // symbol of the kernel that needed it (rocprofv3 lists splitk_reduce_kernel separately; profiles/README.md shows how to add it back)
+    if (prof) { (void)hipEventRecord(rec.e1, st); g_recs.push_back(rec); }
     return rc;
 }
 

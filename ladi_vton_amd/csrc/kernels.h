@@ -120,10 +120,12 @@ int ladi_launch_prepare_mask(const void* image_nchw, int img_f32, const void* ma
 int ladi_launch_mask_down(const h16* src, int B, int H, int W, int s, h16* dst, hipStream_t st);
 // bilinear /8 (align_corners=False == mean of centre 2x2) of pose [B][C][H][W] (NCHW) -> NHWC fp16 [B][h*w][C]
 int ladi_launch_pose_down8(const void* pose_nchw, int f32, int B, int C, int H, int W, h16* dst, hipStream_t st);
-// image = clamp(x/2+0.5, 0, 1) : src NHWC fp16 (ld) 3 valid channels -> fp32 [B][H][W][3]
-int ladi_launch_image_post(const h16* src, int ld, int n_pix, float* dst, hipStream_t st);
+// image = clamp(x/2+0.5, 0, 1) : src NHWC fp16 (ld) 3 valid channels -> fp32 [B][H][W][3], or (dst_u8) uint8 = round(image * 255)
+int ladi_launch_image_post(const h16* src, int ld, int n_pix, void* dst, int dst_u8, hipStream_t st);
 // features[i] *= (1-mask) standalone (mask_features for the module-by-module shim path)
 int ladi_launch_mask_mul(h16* feat, int C, int n_pix, const h16* mask, hipStream_t st);
+// one wave spins for wall_ticks ticks of the 100 MHz counter; out2 (device) = {shader cycles, wall ticks}
+int ladi_launch_clock_probe(unsigned long long wall_ticks, unsigned long long* out2, hipStream_t st);
 int ladi_launch_fill_f32(float* p, size_t n, float v, hipStream_t st);
 int ladi_launch_scale_h16(const h16* src, int lds_, h16* dst, int ldd, size_t n_pix, int C, float s, hipStream_t st);
 // CLIP text embeddings + pseudo-word splice: ids [B][T] (device), first [B] = position of the sentence's first '$' or -1,
@@ -140,8 +142,9 @@ int ladi_launch_maxpool2(const h16* src, int lds_, int n, int H, int W, int C, h
 int ladi_launch_upsample2x_bilinear_ac(const h16* src, int lds_, int n, int H, int W, int C, h16* dst, int ldd, hipStream_t st);
 // glue of the warping module (src/inference.py:242-260), NCHW planes, fp32 or fp16 in / out:
 // torchvision resize(BILINEAR, antialias=True) == aten _upsample_bilinear2d_aa (align_corners=False)
+struct ResizeEpi { int on, C; float pre_mul, pre_add; float sub[4], div[4]; };   // value epilogue, see elementwise.hip
 int ladi_launch_resize_bilinear_aa(const void* src, int in_f32, int planes, int H, int W, void* dst, int out_f32, int Ho, int Wo,
-                                   hipStream_t st);
+                                   hipStream_t st, const ResizeEpi* epi = nullptr);
 // F.grid_sample(x, grid, bilinear, padding_mode="border", align_corners=False); grid fp32 [B][Ho][Wo][2] (x, y)
 int ladi_launch_grid_sample_border(const void* src, int in_f32, int B, int C, int H, int W, const float* grid, int Ho, int Wo, void* dst,
                                    int out_f32, hipStream_t st);

@@ -148,8 +148,35 @@ struct UNet {
     int set_context(const h16* ehs, int n, int L, hipStream_t st);
     int compute_temb(const float* timesteps_host, int count, hipStream_t st);  // fills temb_table rows [0,count)
     // x: [n,h,w,64] padded NHWC input; returns eps Act [n,h,w,4(ld 4)]
-    Act forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_idx);
+    // eps_out (optional): pre-allocated output view (rows of a shared buffer); sample0: index of x's first sample in the context batch
+    Act forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_idx, const Act* eps_out = nullptr, int sample0 = 0);
     ~UNet();
+};
+
+// Sample-group lanes of one UNet forward.  No operation of the forward couples two samples (GroupNorm, LayerNorm and attention are
+// per-sample; the CFG halves meet only in the scheduler kernel), so the n samples of a CFG-stacked batch are run as G independent
+// forwards of n / G samples on G HIP streams, forked from and joined back into the caller's stream with events -- capturable: the
+// denoising step becomes ONE hipGraph with G parallel branches.  Why: at batch 8 a single forward is a chain of ~410 dependent
+// launches, many of which cannot fill 256 CUs (192 tiles of 320x256 on the 64x48 level, ~60-240 workgroups on the 8x6 level) and
+// each of which pays its own ramp-up, drain and kernel boundary; two chains in flight fill each other's idle CUs and hide each
+// other's boundaries.  Every lane owns its activation arena and GroupNorm-statistics buffer (planned by a dry run like every arena of
+// this library), so lanes never share a transient address.
+struct UNetLanes {
+    static constexpr int MAXG = 8;
+    int G = 1;
+    hipStream_t st[MAXG] = {};              // st[0] unused: lane 0 runs on the caller's stream
+    hipEvent_t fork = nullptr, join[MAXG] = {};
+    Arena arena[MAXG]; size_t peak[MAXG] = {};
+    float* stats[MAXG] = {}; size_t stats_cap[MAXG] = {}, stats_peak[MAXG] = {};
+    static int pick(int n);                 // LADI_UNET_LANES (default 2), lowered until it divides n
+    void configure(int n, int g = 0);       // g = 0: pick(n); creates the streams / events
+    // x [n,h,w,64] -> eps [n,h,w,ld] (both caller-owned, contiguous in n).  dry: planning pass (records arena / statistics peaks, no
+    // launches); concurrent = false runs the lanes one after the other on main_st (first evaluation: per-shape tile measurement wants
+    // a quiet chip)
+    void forward(UNet& u, hipStream_t main_st, bool dry, bool concurrent, const Act& x, const Act& eps, const float* temb, const int* tidx);
+    void commit_plan();                     // after the dry pass: (re)allocate what grew; not capturable
+    unsigned long long key() const;         // part of the hipGraph key: lane count and every address a captured lane may touch
+    ~UNetLanes();
 };
 
 struct VAECfg {
@@ -318,6 +345,7 @@ struct TryOn {
     DevPool pool;  // small persistent things
     StepTable* d_table = nullptr; int table_cap = 0; int* d_step = nullptr;
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; unsigned long long graph_key = 0;
+    UNetLanes lanes; int lanes_override = 0;   // sample-group lanes of the denoising loop (0 = LADI_UNET_LANES / default)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool ev_valid = false;
     int last_evals = 0;
     float* trace_eps = nullptr; float* trace_lat = nullptr; int trace_cap = 0;   // caller-owned per-evaluation trace buffers (tests)
@@ -326,7 +354,8 @@ struct TryOn {
     hipStream_t own_stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
     // stage times of the last run (ms): [0] preprocess+VAE encodes+EMASC, [1] denoising loop, [2] decode ; call after a sync
     int stage_ms(float out[3]);
-    int run(const TryOnInputs& in, float* images_out, float* latents_out, hipStream_t st);
+    // images_out: fp32 [B,H,W,3] in [0,1], or (images_u8) uint8 = round(image * 255)
+    int run(const TryOnInputs& in, void* images_out, int images_u8, float* latents_out, hipStream_t st);
     ~TryOn();
 };
 

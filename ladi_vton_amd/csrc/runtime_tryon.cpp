@@ -34,7 +34,7 @@ static unsigned long long mix(unsigned long long h, unsigned long long v) {
     return h;
 }
 
-int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hipStream_t user_st) {
+int TryOn::run(const TryOnInputs& in, void* images_out, int images_u8, float* latents_out, hipStream_t user_st) {
     if (!unet || !vae) { set_error("tryon: unet and vae are required"); return -1; }
     hipStream_t st = user_st;
     try {
@@ -73,13 +73,14 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
     if (!ev[0]) for (auto& e : ev) HIP_OK(hipEventCreate(&e));
 
     try {
+        lanes.configure(n, lanes_override > 0 && (n % lanes_override) == 0 ? lanes_override : 0);
         for (int pass = 0; pass < 2; ++pass) {
             arena.dry = (pass == 0);
             arena.off = 0;
             Ctx c; c.st = st; c.ar = &arena; c.stats = stats; c.stats_cap = stats_cap;
             if (pass == 1) {
                 HIP_OK(hipMemcpyAsync(d_table, table.data(), (size_t)evals * sizeof(StepTable), hipMemcpyHostToDevice, st));
-                HIP_OK(hipMemsetAsync(d_step, 0, sizeof(int), st));
+                HIP_OK(hipMemsetAsync(d_step, 0, 2 * sizeof(int), st));    // evaluation index + the step kernel's arrival ticket
                 std::vector<float> tsf(timesteps.begin(), timesteps.end());
                 if (unet->compute_temb(tsf.data(), evals, st)) return -5;
                 HIP_OK(hipEventRecord(ev[0], st));
@@ -163,18 +164,20 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
             sa.B = B; sa.hw = hw; sa.cfg = cfgf; sa.guidance = in.guidance; sa.latents = latents; sa.cur_sample = cur_sample; sa.ets = ets;
             sa.table = d_table; sa.step_idx = d_step; sa.unet_in = unet_in.p; sa.ld_in = 64; sa.cloth_ch0 = 9 + pose_ch;
             sa.trace_eps = trace_eps; sa.trace_lat = trace_lat; sa.trace_cap = trace_cap;
+            // the UNet forward runs as lanes.G independent sample groups on as many streams (runtime.h UNetLanes); the lanes own their
+            // arenas, the shared noise prediction lives in this one
+            const int eps_ld = (unet->cfg.out_channels + 3) / 4 * 4;
+            Act eps = c.new_act(n, h, w, unet->cfg.out_channels, eps_ld);
             const size_t mk_loop = arena.mark();
-            auto one_step = [&]() {
+            auto one_step = [&](bool concurrent) {
                 arena.release(mk_loop);
-                c.stats_off = 0;
-                if (!c.dry()) if (stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
-                Act eps = unet->forward(c, unet_in, unet->temb_table, d_step);
+                lanes.forward(*unet, st, c.dry(), concurrent, unet_in, eps, unet->temb_table, d_step);
                 if (!c.dry()) { sa.eps = eps.p; sa.ld_eps = eps.ld; c.check(ladi_launch_sched_step(sa, st), "sched_step"); }
             };
-            if (c.dry()) one_step();
-            else if (!in.use_graph || evals < 3) { for (int i = 0; i < evals; ++i) one_step(); }
+            if (c.dry()) one_step(false);
+            else if (!in.use_graph || evals < 3) { for (int i = 0; i < evals; ++i) one_step(i > 0); }
             else {
-                one_step();  // eager first evaluation (also performs one-time function attribute setup)
+                one_step(false);  // eager first evaluation, lanes one after the other (one-time function attribute setup, per-shape tile measurement)
                 unsigned long long key = 0x1234;
                 key = mix(key, (unsigned long long)(uintptr_t)arena.base); key = mix(key, (unsigned long long)B * 1000003ULL + H * 4099ULL + W);
                 key = mix(key, (unsigned long long)cfgf); key = mix(key, (unsigned long long)L);
@@ -184,11 +187,12 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
                 key = mix(key, (unsigned long long)pose_ch * 7 + has_cloth);
                 key = mix(key, (unsigned long long)(uintptr_t)trace_eps); key = mix(key, (unsigned long long)(uintptr_t)trace_lat);
                 key = mix(key, (unsigned long long)trace_cap);
+                key = mix(key, lanes.key());
                 if (!gexec || key != graph_key) {
                     if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
                     if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
                     HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-                    try { one_step(); } catch (...) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); throw; }
+                    try { one_step(true); } catch (...) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); throw; }
                     HIP_OK(hipStreamEndCapture(st, &graph));
                     HIP_OK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
                     graph_key = key;
@@ -217,7 +221,7 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
                         c.stats_off = 0;
                         if (stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
                         Act img = vae->decode(c, z, use_emasc ? skips : nullptr, sh);
-                        c.check(ladi_launch_image_post(img.p, img.ld, B * H * W, images_out, st), "image_post");
+                        c.check(ladi_launch_image_post(img.p, img.ld, B * H * W, images_out, images_u8, st), "image_post");
                     });
                     if (latents_out) c.check(ladi_launch_lat_pix_to_nchw(latents, B, hw, latents_out, st), "latents_out");
                     HIP_OK(hipEventRecord(ev[3], st));
@@ -225,6 +229,7 @@ int TryOn::run(const TryOnInputs& in, float* images_out, float* latents_out, hip
                 }
             }
             if (pass == 0) {
+                lanes.commit_plan();
                 arena.reserve(arena.peak + 4096);
                 if (c.stats_peak > stats_cap) {
                     if (stats) (void)hipFree(stats);

@@ -5,6 +5,7 @@
 #include <stdexcept>
 #include <cstring>
 #include <new>
+#include <cstdlib>
 
 namespace ladi {
 
@@ -142,7 +143,7 @@ int UNet::compute_temb(const float* ts_host, int count, hipStream_t st) {
 namespace {
 
 struct Fwd {
-    Ctx& c; UNet& u; const float* temb; const int* tidx;
+    Ctx& c; UNet& u; const float* temb; const int* tidx; int sample0;
     Act res(const ResBlock& r, const Act& x, const Act* x2) {
         Act out;
         // block output is allocated first so temporaries can be released (stack discipline)
@@ -201,7 +202,8 @@ struct Fwd {
         Act t1 = conv2d(c, b.o1, o1, nullptr, or1);
         ConvOpt oq2; oq2.ln = &b.ln2;
         Act q2 = conv2d(c, b.q2, t1, nullptr, oq2);
-        Act o2 = attn(q2.p, C, (long long)T * C, b.kv_cache, b.kv_cache + C, 2 * C, (long long)u.ctx_L * 2 * C, n, T, u.ctx_L, b.heads);
+        const h16* kv = b.kv_cache + (size_t)sample0 * u.ctx_L * 2 * C;     // this lane's samples of the cached cross-attention K / V
+        Act o2 = attn(q2.p, C, (long long)T * C, kv, kv + C, 2 * C, (long long)u.ctx_L * 2 * C, n, T, u.ctx_L, b.heads);
         ConvOpt or2; or2.res0 = &t1;
         Act t2 = conv2d(c, b.o2, o2, nullptr, or2);
         ConvOpt og; og.act = LADI_ACT_GEGLU; og.ln = &b.ln3;
@@ -220,9 +222,9 @@ struct Fwd {
 
 }  // namespace
 
-Act UNet::forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_idx) {
-    if (ctx_n != x.n && !c.dry()) throw std::runtime_error("UNet::forward: set_context batch mismatch");
-    Fwd f{c, *this, temb_row, temb_idx};
+Act UNet::forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_idx, const Act* eps_out, int sample0) {
+    if ((eps_out ? sample0 + x.n > ctx_n : ctx_n != x.n) && !c.dry()) throw std::runtime_error("UNet::forward: set_context batch mismatch");
+    Fwd f{c, *this, temb_row, temb_idx, sample0};
     const int L = cfg.layers_per_block;
     std::vector<Act> skips;
     ConvOpt o; o.stats = true;
@@ -259,7 +261,80 @@ Act UNet::forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_i
     Act g = group_norm(c, norm_out, h, nullptr, cfg.groups, cfg.eps, 1);
     ConvOpt oc; oc.out_ld = 4;
     if (cfg.out_channels > 4) oc.out_ld = (cfg.out_channels + 3) / 4 * 4;
+    if (eps_out) return f.conv2d_into(conv_out, g, oc, *eps_out);     // a sample-group lane writes its rows of the shared output
     return conv2d(c, conv_out, g, nullptr, oc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sample-group lanes (runtime.h): G forwards of n / G samples on G streams
+// ------------------------------------------------------------------------------------------------
+#define HIP_OK_L(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+int UNetLanes::pick(int n) {
+    int want = 2;
+    if (const char* e = getenv("LADI_UNET_LANES")) want = atoi(e);
+    if (want < 1) want = 1;
+    if (want > MAXG) want = MAXG;
+    while (want > 1 && (n % want)) --want;
+    return want;
+}
+
+void UNetLanes::configure(int n, int g) {
+    G = g > 0 ? g : pick(n);
+    if (G < 1 || G > MAXG || (n % G)) throw std::runtime_error("UNetLanes: the lane count must divide the sample count");
+    if (!fork) HIP_OK_L(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    for (int i = 1; i < G; ++i) {
+        if (!st[i]) HIP_OK_L(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+        if (!join[i]) HIP_OK_L(hipEventCreateWithFlags(&join[i], hipEventDisableTiming));
+    }
+}
+
+void UNetLanes::forward(UNet& u, hipStream_t main_st, bool dry, bool concurrent, const Act& x, const Act& eps, const float* temb, const int* tidx) {
+    const int ng = x.n / G;
+    const bool par = concurrent && !dry && G > 1;
+    if (par) HIP_OK_L(hipEventRecord(fork, main_st));
+    for (int g = 0; g < G; ++g) {
+        hipStream_t sg = (par && g > 0) ? st[g] : main_st;
+        if (par && g > 0) HIP_OK_L(hipStreamWaitEvent(sg, fork, 0));
+        arena[g].dry = dry; arena[g].off = 0;
+        Ctx c; c.st = sg; c.ar = &arena[g]; c.stats = stats[g]; c.stats_cap = stats_cap[g];
+        if (!dry && stats_cap[g]) HIP_OK_L(hipMemsetAsync(stats[g], 0, stats_cap[g] * sizeof(float), sg));
+        Act xg = x; xg.n = ng; xg.p = x.p + (size_t)g * ng * x.h * x.w * x.ld;
+        Act eg = eps; eg.n = ng; eg.p = eps.p + (size_t)g * ng * eps.h * eps.w * eps.ld; eg.st_part = nullptr; eg.st_px = 0;
+        (void)u.forward(c, xg, temb, tidx, &eg, g * ng);
+        if (dry) { peak[g] = arena[g].peak; stats_peak[g] = c.stats_peak; }
+        if (par && g > 0) { HIP_OK_L(hipEventRecord(join[g], sg)); HIP_OK_L(hipStreamWaitEvent(main_st, join[g], 0)); }
+    }
+}
+
+void UNetLanes::commit_plan() {
+    for (int g = 0; g < G; ++g) {
+        arena[g].reserve(peak[g] + 4096);
+        if (stats_peak[g] > stats_cap[g]) {
+            if (stats[g]) (void)hipFree(stats[g]);
+            stats[g] = nullptr;
+            HIP_OK_L(hipMalloc(reinterpret_cast<void**>(&stats[g]), stats_peak[g] * sizeof(float)));
+            stats_cap[g] = stats_peak[g];
+        }
+    }
+}
+
+unsigned long long UNetLanes::key() const {
+    unsigned long long h = 0x9e3779b97f4a7c15ULL * (unsigned long long)G;
+    for (int g = 0; g < G; ++g) {
+        h ^= (unsigned long long)(uintptr_t)arena[g].base + (h << 6) + (h >> 2);
+        h ^= (unsigned long long)(uintptr_t)stats[g] + (h << 6) + (h >> 2);
+    }
+    return h;
+}
+
+UNetLanes::~UNetLanes() {
+    for (int i = 0; i < MAXG; ++i) {
+        if (stats[i]) (void)hipFree(stats[i]);
+        if (join[i]) (void)hipEventDestroy(join[i]);
+        if (st[i]) (void)hipStreamDestroy(st[i]);
+    }
+    if (fork) (void)hipEventDestroy(fork);
 }
 
 }  // namespace ladi

@@ -160,6 +160,13 @@ class NativeUNet(_Base):
         check(self.lib.ladi_unet_time_forward(self.h, n, h, w, iters, ctypes.byref(ms), stream_ptr()), "ladi_unet_time_forward")
         return ms.value
 
+    def time_forward_lanes(self, n, h, w, iters, lanes=0, use_graph=True):
+        """average ms of one forward run the way the denoising loop runs it: `lanes` sample groups on as many streams, one hipGraph"""
+        ms = c_float(0)
+        check(self.lib.ladi_unet_time_forward_lanes(self.h, n, h, w, iters, lanes, 1 if use_graph else 0, ctypes.byref(ms), stream_ptr()),
+              "ladi_unet_time_forward_lanes")
+        return ms.value
+
 
 # ---------------------------------------------------------------------------------------------------------------
 # VAE (AutoencoderKL.encode / .decode with EMASC wiring)

@@ -26,7 +26,10 @@ def shard_inputs(inputs, rank, world):
 
 
 def to_uint8(images):
-    """numpy_to_pil rounding: (x * 255).round() -> uint8, on the device"""
+    """numpy_to_pil rounding: (x * 255).round() -> uint8, on the device.  The fused pipeline already hands over uint8
+    (ladi_tryon_run_u8: the rounding happens in the decode epilogue); only float batches of other callers are converted here."""
+    if images.dtype == torch.uint8:
+        return images
     return (images * 255.0).round().clamp(0, 255).to(torch.uint8)
 
 
@@ -50,7 +53,7 @@ def all_gather_images(local_u8, batch, group=None):
 
 
 def run_sharded(run_local, inputs, group=None, batch=None):
-    """run_local(local_inputs) -> [b_r, H, W, 3] float images in [0,1] on this rank's device; returns the gathered uint8 batch.
+    """run_local(local_inputs) -> [b_r, H, W, 3] images on this rank's device (uint8, or float in [0,1]); returns the gathered uint8 batch.
     `inputs` is the GLOBAL batch: either a dict of [B, ...] tensors (sliced here), or a callable rows(lo, hi) -> dict that materialises
     rows [lo, hi) of the global batch (same values as slicing it; `batch` = B) so that a rank never builds the other ranks' samples."""
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1

@@ -40,6 +40,7 @@ class StableDiffusionTryOnePipeline:
         self._tryon = None
         self.last_stage_ms = None
         self.trace_evals = 0          # > 0: the next fused runs record per-evaluation noise_pred / latents into self.last_trace
+        self.lanes = None             # sample-group lanes of the fused loop's UNet forward (None: library default, LADI_UNET_LANES or 2)
 
     def to(self, *a, **k):
         return self
@@ -180,7 +181,9 @@ class StableDiffusionTryOnePipeline:
 
     # -------------------------------------------------------------------------------------------------------
     def _run_fused(self, image, mask_image, pose_map, cloth, pe, neg, n_cloth, n_lat, n_mask, H, W, steps, guidance, ccr, no_pose,
-                   use_graph, return_device=False):
+                   use_graph, return_device=False, out_uint8=False, lanes=None):
+        """return_device: hand back the device tensor (no host copy); out_uint8: the batch as uint8 [B,H,W,3] = numpy_to_pil's
+        (images * 255).round() computed by the decode epilogue (ladi_tryon_run_u8); lanes: sample-group lanes of the UNet forward"""
         lib = _lib.load()
         if self._tryon is None:
             self._tryon = lib.ladi_tryon_create(self.unet.h, self.vae.h, self.emasc.h if self.emasc else None)
@@ -223,7 +226,7 @@ class StableDiffusionTryOnePipeline:
         inp.no_pose, inp.use_graph = int(bool(no_pose)), int(bool(use_graph))
         ac = self.scheduler.alphas_cumprod.to("cpu", torch.float32).contiguous()
         inp.alphas_cumprod_host = ac.data_ptr()
-        images = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+        images = torch.empty((B, H, W, 3), dtype=torch.uint8 if out_uint8 else torch.float32, device=dev)
         self.last_latents = torch.empty((B, 4, H // 8, W // 8), dtype=torch.float32, device=dev)
         tr = None
         if self.trace_evals > 0:
@@ -233,7 +236,10 @@ class StableDiffusionTryOnePipeline:
             check(lib.ladi_tryon_set_trace(self._tryon, None, None, 0), "ladi_tryon_set_trace")
         # the fused loop rewrites the UNet's cross-attention K/V cache behind the shim's back
         self.unet._ctx_key = None
-        check(lib.ladi_tryon_run(self._tryon, ctypes.byref(inp), ptr(images), ptr(self.last_latents), stream_ptr()), "ladi_tryon_run")
+        if lanes is not None or self.lanes is not None:
+            check(lib.ladi_tryon_set_lanes(self._tryon, int(lanes if lanes is not None else self.lanes)), "ladi_tryon_set_lanes")
+        run = lib.ladi_tryon_run_u8 if out_uint8 else lib.ladi_tryon_run
+        check(run(self._tryon, ctypes.byref(inp), ptr(images), ptr(self.last_latents), stream_ptr()), "ladi_tryon_run")
         if tr is not None:   # [evals, B, 4, h, w] like the reference's noise_pred / latents (tryon_pipe.py:732-740)
             nchw = tr.view(2, self.trace_evals, B, h8, w8, 4).permute(0, 1, 2, 5, 3, 4)
             self.last_trace = dict(noise_pred=nchw[0].contiguous(), latents=nchw[1].contiguous())

@@ -110,6 +110,27 @@ def resize_antialias(x, size):
     return out
 
 
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_preprocess(cloth, size=224, mean=CLIP_MEAN, std=CLIP_STD):
+    """src/inference.py:268-272 in one kernel: resize((cloth + 1) / 2, (size, size), antialias=True).clamp(0, 1), CLIP mean / std
+    normalisation, fp16 pixel_values [B, 3, size, size] for the vision encoder.  cloth [B, 3, H, W] in [-1, 1], fp32 / fp16."""
+    if cloth.dim() != 4 or cloth.shape[1] != 3:
+        raise ValueError("expected a [B, 3, H, W] tensor")
+    lib = _lib.load()
+    x = cloth.to(torch.device("cuda", torch.cuda.current_device()))
+    if x.dtype not in (torch.float16, torch.float32):
+        x = x.float()
+    x = x.contiguous()
+    B, _, H, W = x.shape
+    out = torch.empty((B, 3, size, size), dtype=torch.float16, device=x.device)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(lib.ladi_op_clip_preprocess(ptr(x), dtype_code(x), B, H, W, int(size), m3, s3, ptr(out), stream_ptr()), "ladi_op_clip_preprocess")
+    return out
+
+
 def grid_sample_border(x, grid):
     """F.grid_sample(x, grid, padding_mode="border") (bilinear, align_corners=False; src/inference.py:260): x [B, C, H, W], grid
     [B, Ho, Wo, 2] in [-1, 1] (x, y) -> [B, C, Ho, Wo] of x's dtype."""
