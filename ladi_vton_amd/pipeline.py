@@ -251,6 +251,10 @@ class StableDiffusionTryOnePipeline:
             self.last_stage_ms = list(ms)
         return out
 
+    def lib_lanes(self):
+        """sample-group lanes the last fused run used"""
+        return _lib.load().ladi_tryon_lanes(self._tryon) if self._tryon else None
+
     def __del__(self):
         if getattr(self, "_tryon", None):
             _lib.load().ladi_tryon_destroy(self._tryon)

@@ -112,7 +112,7 @@ def cpu_quota_threads():
     return n
 
 
-def record_parity(key, value, name="parity_r03.json"):
+def record_parity(key, value, name="parity_r04.json"):
     """append a measured parity value to gpurun_out/<name> (copied to profiles/r03_parity.json after the run): every tolerance asserted in
     the GPU tests has its measured value on record"""
     import json
