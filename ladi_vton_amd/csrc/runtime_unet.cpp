@@ -271,7 +271,7 @@ Act UNet::forward(Ctx& c, const Act& x, const float* temb_row, const int* temb_i
 #define HIP_OK_L(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 int UNetLanes::pick(int n) {
-    int want = 2;
+    int want = 1;
     if (const char* e = getenv("LADI_UNET_LANES")) want = atoi(e);
     if (want < 1) want = 1;
     if (want > MAXG) want = MAXG;

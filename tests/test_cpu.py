@@ -2,6 +2,7 @@
 input validation, sharding) and the C-ABI surface (library loads, exports every declared symbol; no compute without a GPU)."""
 import ctypes
 import os
+from collections import OrderedDict
 import re
 import subprocess
 import sys
@@ -11,6 +12,7 @@ import pytest
 import torch
 from safetensors.torch import load_file
 
+from ladi_vton_amd import configs as LC
 from oracle import configs as C
 from oracle import models as M
 from oracle import pipeline as P
@@ -629,3 +631,162 @@ def test_dataset_preprocessing_matches_real_reference_classes(tmp_path):
     assert np.array_equal(dilate_box(m, 5, 5), ref)
     with pytest.raises(ValueError):
         VitonHDDataset(str(tmp_path / "viton"), "test", outputlist=("dense_uv",))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Second source for the arithmetic no reference-held vector pins: the diffusers blocks rebuilt from STOCK torch.nn
+# modules (nn.GroupNorm / nn.Conv2d / nn.LayerNorm / nn.MultiheadAttention with kdim / vdim) loaded from the App. A.6 key list, and the
+# scheduler recurrences checked against their papers' closed forms.  Two independent derivations instead of one restatement; this does
+# not lift the "parity unpinned" cap (neither is reference-held), it shrinks the room for a shared misreading.
+# ---------------------------------------------------------------------------------------------------------------
+class _NNResnet(torch.nn.Module):
+    """ResnetBlock2D from stock modules: norm1 -> SiLU -> conv1 (+ time_emb_proj(SiLU(temb))) -> norm2 -> SiLU -> conv2, + shortcut"""
+
+    def __init__(self, cin, cout, temb, groups, eps):
+        super().__init__()
+        nn = torch.nn
+        self.norm1, self.conv1 = nn.GroupNorm(groups, cin, eps=eps), nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb, cout) if temb else None
+        self.norm2, self.conv2 = nn.GroupNorm(groups, cout, eps=eps), nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+        self.act = nn.SiLU()
+
+    def forward(self, x, temb):
+        h = self.conv1(self.act(self.norm1(x)))
+        if self.time_emb_proj is not None:
+            h = h + self.time_emb_proj(self.act(temb))[:, :, None, None]
+        h = self.conv2(self.act(self.norm2(h)))
+        return (self.conv_shortcut(x) if self.conv_shortcut is not None else x) + h
+
+
+def _mha_from(sd, p, C, heads, kdim=None, bias_qkv=False, out="to_out.0", names=("to_q", "to_k", "to_v")):
+    """nn.MultiheadAttention carrying the diffusers attention weights `p`.{to_q,to_k,to_v,to_out.0} (q scaled by head_dim^-0.5 inside)"""
+    m = torch.nn.MultiheadAttention(C, heads, bias=True, batch_first=True, kdim=kdim, vdim=kdim)
+    wq, wk, wv = (sd[p + "." + n + ".weight"] for n in names)
+    with torch.no_grad():
+        if kdim is None or kdim == C:
+            m.in_proj_weight.copy_(torch.cat([wq, wk, wv]))
+        else:
+            m.q_proj_weight.copy_(wq); m.k_proj_weight.copy_(wk); m.v_proj_weight.copy_(wv)
+        if bias_qkv:
+            m.in_proj_bias.copy_(torch.cat([sd[p + "." + n + ".bias"] for n in names]))
+        else:
+            m.in_proj_bias.zero_()
+        m.out_proj.weight.copy_(sd[p + "." + out + ".weight"]); m.out_proj.bias.copy_(sd[p + "." + out + ".bias"])
+    return m.eval()
+
+
+def test_oracle_blocks_match_torch_nn_modules():
+    from oracle import models as M
+    nn = torch.nn
+    g = torch.Generator().manual_seed(3)
+    C0, C1, temb_dim, groups, heads, cross, n, h, w, L = 64, 128, 256, 32, 2, 96, 2, 8, 6, 7
+    # ---- ResnetBlock2D with a channel change (conv_shortcut) and a time embedding
+    shapes = OrderedDict()
+    LC._resnet(shapes, "r", C0, C1, temb_dim)
+    sd = C.synth_state_dict(shapes, "second.")
+    blk = _NNResnet(C0, C1, temb_dim, groups, 1e-5).eval()
+    blk.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    x = torch.randn((n, C0, h, w), generator=g)
+    temb = torch.randn((n, temb_dim), generator=g)
+    with torch.no_grad():
+        want = blk(x, temb)
+    got = M.resnet(sd, "r", x, temb, groups, 1e-5)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), float((got - want).abs().max())
+    # ---- Transformer2DModel + BasicTransformerBlock (self-attention, cross-attention on `cross`-wide context, GEGLU)
+    shapes = OrderedDict()
+    LC._transformer(shapes, "t", C1, cross)
+    sd = C.synth_state_dict(shapes, "second.")
+    b = "t.transformer_blocks.0"
+    gn, proj_in, proj_out = nn.GroupNorm(groups, C1, eps=1e-6), nn.Linear(C1, C1), nn.Linear(C1, C1)
+    ln = [nn.LayerNorm(C1) for _ in range(3)]
+    ff1, ff2, gelu = nn.Linear(C1, 8 * C1), nn.Linear(4 * C1, C1), nn.GELU()
+    for mod, key in ((gn, "t.norm"), (proj_in, "t.proj_in"), (proj_out, "t.proj_out"), (ln[0], b + ".norm1"), (ln[1], b + ".norm2"),
+                     (ln[2], b + ".norm3"), (ff1, b + ".ff.net.0.proj"), (ff2, b + ".ff.net.2")):
+        mod.load_state_dict({"weight": sd[key + ".weight"], "bias": sd[key + ".bias"]}, strict=True)
+    attn1 = _mha_from(sd, b + ".attn1", C1, heads)
+    attn2 = _mha_from(sd, b + ".attn2", C1, heads, kdim=cross)
+    x = torch.randn((n, C1, h, w), generator=g)
+    ehs = torch.randn((n, L, cross), generator=g)
+    with torch.no_grad():
+        t = proj_in(gn(x).permute(0, 2, 3, 1).reshape(n, h * w, C1))
+        a = ln[0](t); t = attn1(a, a, a, need_weights=False)[0] + t
+        a = ln[1](t); t = attn2(a, ehs, ehs, need_weights=False)[0] + t
+        u, gate = ff1(ln[2](t)).chunk(2, dim=-1)
+        t = ff2(u * gelu(gate)) + t
+        want = proj_out(t).reshape(n, h, w, C1).permute(0, 3, 1, 2) + x
+    got = M.transformer2d(sd, "t", x, ehs, heads, groups)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), float((got - want).abs().max())
+    # ---- VAE AttentionBlock (one head of width C, biased q / k / v, residual)
+    shapes = OrderedDict()
+    LC._vae_attn(shapes, "a", C1)
+    sd = C.synth_state_dict(shapes, "second.")
+    vgn = nn.GroupNorm(groups, C1, eps=1e-6)
+    vgn.load_state_dict({"weight": sd["a.group_norm.weight"], "bias": sd["a.group_norm.bias"]})
+    mha = _mha_from(sd, "a", C1, 1, bias_qkv=True, out="proj_attn", names=("query", "key", "value"))
+    with torch.no_grad():
+        tok = vgn(x).reshape(n, C1, h * w).transpose(1, 2)
+        want = mha(tok, tok, tok, need_weights=False)[0].transpose(1, 2).reshape(n, C1, h, w) + x
+    got = M.vae_attention(sd, "a", x, groups)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), float((got - want).abs().max())
+
+
+def _closed_form(ac, a, x0, e):
+    return a ** 0.5 * x0 + (1 - a) ** 0.5 * e
+
+
+@pytest.mark.parametrize("steps", [50, 20])
+def test_scheduler_exact_on_analytic_eps(steps):
+    """(1) A model that returns the TRUE noise e of x_t = sqrt(a_t) x0 + sqrt(1 - a_t) e makes every deterministic DDIM step land on the same
+    closed form at t - ratio (DDIM eq. 12), and PNDM's transfer formula (eq. 9) is that step rationalised, with linear-multistep weights
+    that sum to 1: both schedulers must end exactly at sqrt(a_final) x0 + sqrt(1 - a_final) e, a_final = alphas_cumprod[0]
+    (set_alpha_to_one = False).  Checked for the oracle classes and for the product's host schedulers.
+    (2) On a noise prediction that is LINEAR in t, the 4th-order Adams-Bashforth combination (55, -59, 37, -9) / 24 over equally spaced
+    evaluations equals the prediction at the step's midpoint t - ratio / 2, and the warm-up orders (1, 3/2 -1/2, 23/12 -16/12 5/12) equal
+    it at t, t - ratio / 2, t - ratio / 2: the effective epsilon recovered from each PLMS step must match."""
+    from oracle import pipeline as P
+    import ladi_vton_amd.schedulers as S
+    g = torch.Generator().manual_seed(steps)
+    x0 = torch.randn((1, 4, 8, 6), generator=g, dtype=torch.float64)
+    e = torch.randn((1, 4, 8, 6), generator=g, dtype=torch.float64)
+    ac = P.alphas_cumprod().double()
+    want = _closed_form(ac, ac[0], x0, e)
+    for kind in ("ddim", "pndm"):
+        sch = P.make_scheduler(kind)
+        sch.set_timesteps(steps)
+        sch.ac = sch.ac.double(); sch.final_ac = sch.ac[0]
+        x = _closed_form(ac, ac[sch.timesteps[0]], x0, e)
+        for t in sch.timesteps:
+            x = sch.step(e, t, x)
+        assert torch.allclose(x, want, rtol=0, atol=1e-9), (kind, float((x - want).abs().max()))
+        prod = S.DDIMScheduler() if kind == "ddim" else S.PNDMScheduler()
+        prod.set_timesteps(steps)
+        xp = _closed_form(ac, ac[int(prod.timesteps[0])], x0, e).float()
+        for t in prod.timesteps:
+            xp = prod.step(e.float(), t, xp).prev_sample
+        assert torch.allclose(xp.double(), want, rtol=0, atol=2e-4), (kind, float((xp.double() - want).abs().max()))
+    # (2) effective epsilon of each PLMS step on eps(t) = e0 + t * e1
+    e1 = torch.randn((1, 4, 8, 6), generator=g, dtype=torch.float64) * 1e-3
+    sch = P.make_scheduler("pndm")
+    sch.set_timesteps(steps)
+    sch.ac = sch.ac.double(); sch.final_ac = sch.ac[0]
+    ratio = 1000 // steps
+    x = torch.randn((1, 4, 8, 6), generator=g, dtype=torch.float64)
+    for i, t in enumerate(sch.timesteps):
+        eps_t = e + t * e1
+        cur = sch.cur_sample if i == 1 else x
+        xn = sch.step(eps_t, t, x)
+        # invert the transfer formula (PNDM eq. 9) for the epsilon the step used
+        t_from, t_to = (t + ratio, t) if i == 1 else (t, t - ratio)
+        a_t, a_p = ac[t_from], (ac[t_to] if t_to >= 0 else ac[0])
+        coeff = (a_p / a_t) ** 0.5
+        denom = a_t * (1 - a_p) ** 0.5 + (a_t * (1 - a_t) * a_p) ** 0.5
+        used = (coeff * cur - xn) * denom / (a_p - a_t)
+        if i == 0:
+            mid = float(t)                       # first evaluation: plain step with eps(t)
+        elif i == 1:
+            mid = t + ratio / 2.0                # second evaluation: (eps(t) + eps(t + ratio)) / 2 from the saved sample
+        else:
+            mid = t - ratio / 2.0                # orders 2, 3 and 4 all extrapolate a linear function to the step's midpoint
+        assert torch.allclose(used, e + mid * e1, rtol=0, atol=1e-8), (i, t, float((used - (e + mid * e1)).abs().max()))
+        x = xn
