@@ -262,6 +262,9 @@ int ladi_unet_time_forward_lanes(ladi_unet* u, int n, int h, int w, int iters, i
 /* measured tile-shape selection (default on): the first launch of a new problem shape outside a stream capture times the
  * admissible tile configurations and caches the fastest; off = static cost model */
 void ladi_igemm_set_autotune(int on);
+/* split-K launches combine their K slices inside the launch (last-arriving slice of a tile runs the fused epilogue; csrc/igemm_common.h);
+ * on = 1 switches to the separate reduce pass of rounds 1-3 (A/B measurements, parity tests of one form against the other) */
+void ladi_igemm_set_splitk_two_pass(int on);
 void ladi_profile_igemm_enable(int on);
 int ladi_profile_igemm_collect(double* out, int n_out);
 /* the same records grouped by the exact kernel symbol rocprofv3 reports (the X-stationary kernel has several): text lines
@@ -282,6 +285,7 @@ typedef struct {
     const void* res0; const void* res1; int ldr0, ldr1; const void* mask; void* out; int ldo; int out_f32;
     float* stats; int stats_groups; int splitk, tile_map /* both ignored: set by the launcher */;
     const void* ln_gamma; const void* ln_beta; float ln_eps; float bias_mul /* multiplier of bias, 0 = 1 */; void* ln_scratch;
+    float* sk_ws; int* sk_cnt;   /* both ignored: set by the launcher (in-launch split-K combine) */
     /* optional LayerNorm of the pixel operand (single source, 1x1): fused into the X-stationary linear kernel where the tuner finds that
        faster, else run as its own kernel into ln_scratch ([P][C0] fp16, caller-provided; null = only the fused form is admissible) */
 } ladi_igemm_desc;

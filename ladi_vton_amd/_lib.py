@@ -77,7 +77,8 @@ class IGemmDesc(Structure):
                 ("rowadd_stride", c_int), ("act", c_int), ("out_scale", c_float),
                 ("res0", c_void_p), ("res1", c_void_p), ("ldr0", c_int), ("ldr1", c_int), ("mask", c_void_p),
                 ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("stats", c_void_p), ("stats_groups", c_int), ("splitk", c_int), ("tile_map", c_int),
-                ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("bias_mul", c_float), ("ln_scratch", c_void_p)]
+                ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("bias_mul", c_float), ("ln_scratch", c_void_p),
+                ("sk_ws", c_void_p), ("sk_cnt", c_void_p)]
 
 
 # every symbol include/ladi_native.h declares: name -> (restype, argtypes)
@@ -133,6 +134,7 @@ SIGNATURES = {
     "ladi_vae_set_range_shift": (c_int, [_P, c_int]),
     "ladi_vae_last_range_shift": (c_int, [_P]),
     "ladi_igemm_set_autotune": (None, [c_int]),
+    "ladi_igemm_set_splitk_two_pass": (None, [c_int]),
     "ladi_profile_igemm_enable": (None, [c_int]),
     "ladi_profile_igemm_collect": (c_int, [POINTER(ctypes.c_double), c_int]),
     "ladi_profile_igemm_symbols": (c_int, [ctypes.c_char_p, c_int]),

@@ -565,6 +565,7 @@ int ladi_tryon_set_trace(ladi_tryon* t, float* eps_trace, float* latents_trace, 
 }
 
 void ladi_igemm_set_autotune(int on) { ladi_igemm_autotune(on); }
+void ladi_igemm_set_splitk_two_pass(int on) { ladi_igemm_splitk_two_pass(on); }
 void ladi_profile_igemm_enable(int on) { ladi_igemm_profile_enable(on); }
 int ladi_profile_igemm_collect(double* out, int n_out) { return ladi_igemm_profile_collect(out, n_out); }
 int ladi_profile_igemm_symbols(char* buf, int n) { return ladi_igemm_profile_symbols(buf, n); }

@@ -112,4 +112,7 @@ struct IGemmArgs {
     float bias_mul;      // multiplier of `bias` (0 means 1): the VAE keeps its residual stream scaled by 2^-k when the fp16 range is tight
                          // (runtime_vae.cpp); a convolution whose INPUT is the scaled stream then needs bias * 2^-k
     h16* ln_scratch;
+    // in-launch split-K combine (set by the launcher, igemm_common.h igemm_splitk_combine): fp32 slabs [splitk][tiles][workgroup image] and
+    // the per-tile arrival counters (zero on entry, left zero); sk_cnt == nullptr with splitk > 1 = two-pass form (splitk_reduce_kernel)
+    float* sk_ws; int* sk_cnt;
 };

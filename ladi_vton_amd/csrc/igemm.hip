@@ -112,7 +112,7 @@ struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; in
 // tile configurations (0 = choose: measured per shape when autotuning is on, else the cost model below).
 // {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K,
 //  K step, offered to the tuner}
-constexpr int NCFG = 87;
+constexpr int NCFG = 92;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1, 0, false},
     {128, 256, 2, true, 0.80f, 4, 1, 1, 32, true},   // 1: <2,2,2,4> BK32 NST3
@@ -213,9 +213,36 @@ const CfgInfo kCfg[NCFG + 1] = {
     {128, 192, 2, false, 0.00f, 3, 85, 1, 64, true},  // 85: halo 128x192, 4 waves, two workgroups per CU
     {128, 128, 2, false, 0.00f, 2, 84, 2, 64, true},  // 86: cfg 84 + split-K 2
     {128, 128, 2, false, 0.00f, 2, 84, 4, 64, true},  // 87: cfg 84 + split-K 4
+    // 88..92 (round 4): halo kernel with the buffer sized for rows <= 24 pixels (a third weight slot at two workgroups per CU), and the
+    // 12-wave 320x192 form: 256 workgroups on the 64x48 level at batch 8 (the 320x256 tiles leave a quarter of the chip idle there)
+    {128, 128, 2, false, 0.00f, 2, 88, 1, 64, true},  // 88: halo 128x128, 4 waves, W <= 24, 3 weight slots
+    {128, 192, 2, false, 0.00f, 3, 89, 1, 64, true},  // 89: halo 128x192, 4 waves, W <= 24, 3 weight slots
+    {128, 128, 2, false, 0.00f, 2, 88, 2, 64, true},  // 90: cfg 88 + split-K 2
+    {128, 128, 2, false, 0.00f, 2, 88, 4, 64, true},  // 91: cfg 88 + split-K 4
+    {320, 192, 1, false, 0.00f, 1, 92, 1, 64, true},  // 92: halo 320x192, 12 waves
 };
 inline bool is_lc(int base) { return base >= 62 && base <= 68; }
-inline bool is_halo(int base) { return (base >= 74 && base <= 78) || base == 84 || base == 85; }
+// kernels whose every wave reaches the shared epilogue can combine their K slices in the launch (igemm_common.h igemm_splitk_combine); the
+// loader / consumer kernel (its loader waves hold no accumulators) and the X-stationary kernel keep the two-pass form
+inline bool sk_inline_ok(int base) { return base != 23 && !is_lc(base); }
+// arrival counters for launches that bring none (op-level entry points): zeroed once, every launch leaves them zeroed.  One stream at a
+// time -- the module graphs pass their own (launch_conv_into)
+int* g_sk_cnt = nullptr;
+constexpr int SK_MAX_TILES = 1024;
+bool ensure_sk_cnt(hipStream_t st) {
+    if (g_sk_cnt) return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    if (hipMalloc(reinterpret_cast<void**>(&g_sk_cnt), SK_MAX_TILES * sizeof(int)) != hipSuccess) { g_sk_cnt = nullptr; return false; }
+    if (hipMemset(g_sk_cnt, 0, SK_MAX_TILES * sizeof(int)) != hipSuccess) return false;
+    return true;
+}
+int g_sk_two_pass = -1;       // -1: environment LADI_SPLITK_TWO_PASS decides (read once)
+bool sk_two_pass_forced() {
+    if (g_sk_two_pass < 0) g_sk_two_pass = getenv("LADI_SPLITK_TWO_PASS") != nullptr ? 1 : 0;
+    return g_sk_two_pass == 1;
+}
+inline bool is_halo(int base) { return (base >= 74 && base <= 78) || base == 84 || base == 85 || base == 88 || base == 89 || base == 92; }
 
 // rocprofv3's name of the kernel a configuration launches (bench.py groups its per-launch timings by symbol)
 std::string cfg_symbol(int c) {
@@ -229,13 +256,16 @@ std::string cfg_symbol(int c) {
         case 56: return "igemm8_kernel<2, 1, 0>";
         case 57: return "igemm8_kernel<5, 1, 0>";
         case 58: return "igemm8_kernel<3, 2, 0>";
-        case 74: return "igemm_halo_kernel<2, 2, 2, 3, 4>";
-        case 75: return "igemm_halo_kernel<4, 2, 1, 3, 4>";
-        case 76: return "igemm_halo_kernel<5, 2, 1, 2, 4>";
-        case 77: return "igemm_halo_kernel<2, 1, 2, 4, 4>";
-        case 78: return "igemm_halo_kernel<4, 1, 1, 3, 4>";
-        case 84: return "igemm_halo_kernel<2, 2, 1, 2, 2>";
-        case 85: return "igemm_halo_kernel<2, 3, 1, 2, 2>";
+        case 74: return "igemm_halo_kernel<2, 2, 2, 3, 4, 48>";
+        case 75: return "igemm_halo_kernel<4, 2, 1, 3, 4, 48>";
+        case 76: return "igemm_halo_kernel<5, 2, 1, 2, 4, 48>";
+        case 77: return "igemm_halo_kernel<2, 1, 2, 4, 4, 48>";
+        case 78: return "igemm_halo_kernel<4, 1, 1, 3, 4, 48>";
+        case 84: return "igemm_halo_kernel<2, 2, 1, 2, 2, 48>";
+        case 85: return "igemm_halo_kernel<2, 3, 1, 2, 2, 48>";
+        case 88: return "igemm_halo_kernel<2, 2, 1, 3, 2, 24>";
+        case 89: return "igemm_halo_kernel<2, 3, 1, 3, 2, 24>";
+        case 92: return "igemm_halo_kernel<5, 1, 1, 2, 6, 48>";
         case 62: return "igemm_lc_kernel<2, 2, 2, 2, 2, 4>";
         case 63: return "igemm_lc_kernel<2, 2, 2, 2, 2, 5>";
         case 64: return "igemm_lc_kernel<2, 2, 4, 2, 2, 3>";
@@ -271,6 +301,9 @@ int launch_base(int cfg, const IGemmArgs& a, int batch, hipStream_t st) {
         case 78: return ladi_launch_igemm_halo(a, 4, 1, 1, batch, st);
         case 84: return ladi_launch_igemm_halo(a, 2, 2, 10, batch, st);
         case 85: return ladi_launch_igemm_halo(a, 2, 3, 10, batch, st);
+        case 88: return ladi_launch_igemm_halo(a, 2, 2, 11, batch, st);
+        case 89: return ladi_launch_igemm_halo(a, 2, 3, 11, batch, st);
+        case 92: return ladi_launch_igemm_halo(a, 5, 1, 12, batch, st);
         case 62: return ladi_launch_igemm_lc(a, 2, 2, 4, batch, st);
         case 63: return ladi_launch_igemm_lc(a, 2, 2, 5, batch, st);
         case 64: return ladi_launch_igemm_lc(a, 4, 2, 3, batch, st);
@@ -371,7 +404,7 @@ static bool cfg_admissible(const IGemmArgs& a, int batch, int c, bool strict) {
     }
     if (a.ln_gamma && !a.ln_scratch) return false;                    // no scratch: only the fused (X-stationary) form
     if (is_lc(ci.base) && (a.ups || batch != 1)) return false;        // loader / consumer kernel: no folded upsample, no batched launches
-    if (is_halo(ci.base) && !ladi_igemm_halo_eligible(a, batch)) return false;   // halo-resident kernel: 3x3 stride-1 convolutions on narrow images
+    if (is_halo(ci.base) && (!ladi_igemm_halo_eligible(a, batch) || ((ci.base == 88 || ci.base == 89) && a.Ws > 24))) return false;   // halo-resident kernel: 3x3 stride-1 convolutions on narrow images
     if (geglu && !ci.geglu_ok) return false;
     if (ci.bk == 64 && ((a.C0 % 64) || (a.C1 % 64))) return false;
     if (ci.split > 1 && (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel)) return false;
@@ -382,15 +415,21 @@ static bool cfg_admissible(const IGemmArgs& a, int batch, int c, bool strict) {
     return true;
 }
 
+// slab bytes configuration c needs: the two-pass form writes [split][P][Q] floats, the in-launch form whole (padded) tile images
+static size_t splitk_cfg_bytes(const IGemmArgs& a, int c) {
+    const CfgInfo& ci = kCfg[c];
+    const size_t tiles = (size_t)((a.Q + ci.bq - 1) / ci.bq) * (size_t)((a.P + ci.bp - 1) / ci.bp);
+    return (size_t)ci.split * std::max((size_t)a.P * (size_t)a.Q, tiles * (size_t)ci.bq * (size_t)ci.bp) * sizeof(float);
+}
 size_t ladi_igemm_splitk_ws_bytes(const IGemmArgs& a, int batch) {
     if (batch != 1 || a.act == LADI_ACT_GEGLU || a.out_f32 || a.bias_per_pixel || a.P <= 0 || a.Q <= 0) return 0;
-    int smax = 0;
+    size_t need = 0;
     for (int c = 1; c <= NCFG; ++c)
-        if (kCfg[c].split > 1 && kCfg[c].base != 23 && splitk_admissible(a, c)) smax = std::max(smax, kCfg[c].split);
-    return (size_t)smax * (size_t)a.P * (size_t)a.Q * sizeof(float);
+        if (kCfg[c].split > 1 && kCfg[c].base != 23 && splitk_admissible(a, c)) need = std::max(need, splitk_cfg_bytes(a, c));
+    return need;
 }
 
-int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st, int* stats_row_px, float* ws, size_t ws_bytes) {
+int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st, int* stats_row_px, float* ws, size_t ws_bytes, int* sk_cnt) {
     IGemmArgs a = a_in;
     const int cfg_in = cfg;
     if (stats_row_px) *stats_row_px = 0;
@@ -425,9 +464,9 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                         if (!kCfg[c].tune || !cfg_admissible(a, batch, c, true)) continue;
                         // X-stationary kernel: no fused statistics there, charge the separate statistics pass the consumer then needs (~3 TB/s read)
                         const float penalty_ms = (kCfg[c].base == 23 && a.stats) ? 3.f * (float)((double)a.P * a.Q * 2.0 / 3.0e9) : 0.f;
-                        if (ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes) != 0) continue;   // warm-up (also sets function attributes)
+                        if (ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes, sk_cnt) != 0) continue;   // warm-up (also sets function attributes)
                         (void)hipEventRecord(e0, st);
-                        for (int r = 0; r < 3; ++r) (void)ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes);
+                        for (int r = 0; r < 3; ++r) (void)ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes, sk_cnt);
                         (void)hipEventRecord(e1, st);
                         if (hipEventSynchronize(e1) != hipSuccess) continue;
                         float ms = 0.f;
@@ -447,7 +486,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                             float pen = 0.f;
                             if (kCfg[c].base == 23 && a.stats) pen = (float)((double)a.P * a.Q * 2.0 / 3.0e9);
                             (void)hipEventRecord(e0, st);
-                            for (int r = 0; r < 10; ++r) (void)ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes);
+                            for (int r = 0; r < 10; ++r) (void)ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes, sk_cnt);
                             (void)hipEventRecord(e1, st);
                             float ms = 0.f;
                             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
@@ -493,16 +532,23 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     if (geglu && !kCfg[cfg].geglu_ok) return -8;
     if (kCfg[cfg].bk == 64 && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
     const int split = kCfg[cfg].split;
+    bool sk_inline = false;
     if (split > 1) {
         if (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel) return -9;
-        const size_t need = (size_t)split * a.P * a.Q * sizeof(float);
+        const size_t need = splitk_cfg_bytes(a, cfg);
         if (!ws || ws_bytes < need) {           // no (or too small a) caller slab: process-wide grow-only fallback
             if (!ensure_ws(need, st)) return -13;
             ws = g_ws;
         }
+        const long long tiles = (long long)((a.Q + kCfg[cfg].bq - 1) / kCfg[cfg].bq) * ((a.P + kCfg[cfg].bp - 1) / kCfg[cfg].bp);
+        sk_inline = sk_inline_ok(kCfg[cfg].base) && !sk_two_pass_forced() && tiles <= SK_MAX_TILES;
+        if (sk_inline && !sk_cnt) {
+            if (ensure_sk_cnt(st)) sk_cnt = g_sk_cnt;
+            else sk_inline = false;             // first use inside a capture without caller counters: two-pass form
+        }
     }
     if (a.stats) {  // fused output statistics need whole 32*TP-pixel row blocks inside one sample
-        const int px = (split > 1 ? 1 : kCfg[cfg].tp) * 32;
+        const int px = ((split > 1 && !sk_inline) ? 1 : kCfg[cfg].tp) * 32;
         if (geglu || batch != 1 || a.out_f32 || ((a.Ho * a.Wo) % px)) a.stats = nullptr;
         else if (stats_row_px) *stats_row_px = px;
     }
@@ -518,7 +564,10 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     }
     IGemmArgs full = a;   // epilogue parameters for the split-K reduce pass
     int lbatch = batch;
-    if (split > 1) {
+    a.sk_ws = nullptr; a.sk_cnt = nullptr;
+    if (split > 1 && sk_inline) {            // in-launch combine: the kernel keeps the real epilogue, the last-arriving slice of a tile runs it
+        a.splitk = split; lbatch = split; a.sk_ws = ws; a.sk_cnt = sk_cnt;
+    } else if (split > 1) {
         a.out = ws; a.ldo = a.Q; a.out_f32 = 1; a.bs_out = (long long)a.P * a.Q; a.splitk = split; lbatch = split;
         a.bias = nullptr; a.rowadd = nullptr; a.act = LADI_ACT_NONE; a.out_scale = 1.f; a.res0 = nullptr; a.res1 = nullptr;
         a.mask = nullptr; a.stats = nullptr;
@@ -526,7 +575,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     const int batch_l = lbatch;
     int rc;
     rc = launch_base(cfg, a, batch_l, st);
-    if (rc == 0 && split > 1) {
+    if (rc == 0 && split > 1 && !sk_inline) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((full.P + 31) / 32), (unsigned)((full.Q + 63) / 64)), dim3(256), 0, st, ws, split, full);
         if (hipGetLastError() != hipSuccess) rc = -11;
     }
@@ -539,6 +588,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream around every igemm launch
 void ladi_igemm_profile_enable(int on) { g_prof = on != 0; }
 void ladi_igemm_autotune(int on) { g_autotune = on != 0; }
+void ladi_igemm_splitk_two_pass(int on) { g_sk_two_pass = on ? 1 : 0; }
 int ladi_igemm_tuned_count() { return (int)g_tuned.size(); }
 int ladi_igemm_profile_symbols(char* buf, int n) {
     std::map<std::string, std::array<double, 3>> by;

@@ -396,9 +396,83 @@ __device__ __forceinline__ void igemm_epilogue_fast(const IGemmArgs& a, f32x16 (
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// In-launch split-K combine (round 4; replaces the separate splitk_reduce_kernel pass for the kernels whose every wave reaches the
+// epilogue).  Each K-slice workgroup PUBLISHES its fp32 accumulators to its slab with write-through (sc1) 16-byte stores -- one private,
+// fully coalesced [wave][fragment][lane] image per (slice, tile), no tile is shared between workgroups of one slice -- drains them
+// (`s_waitcnt vmcnt(0)` in every wave, then the workgroup barrier) and takes a ticket on the tile's arrival counter (relaxed, agent
+// scope).  The workgroup that draws the last ticket reads the S slabs back with sc1 loads (served past the L1; the producers' data is
+// already at the memory side) IN SLICE ORDER -- its own included, so the sum does not depend on who arrives last: bitwise reproducible --
+// re-arms the counter and runs the ordinary fused epilogue; everyone else is done.  This is the write-through form of the hand-off in
+// cdna_hip_programming.md (split-K seam: sc1 slab stores -> vmcnt(0) -> barrier -> relaxed agent fetch_add; reducer sc1 loads): correct
+// for ANY placement of a tile's slices over CUs / XCDs.  Counters live in a caller-owned, zero-initialised buffer that every launch
+// leaves zeroed (hipGraph replay needs no memset node).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int WQ, int WP, int TQ, int TP>
+__device__ __forceinline__ bool igemm_splitk_combine(const IGemmArgs& a, f32x16 (&acc)[TQ][TP], h16* smem, const int q0, const int pt,
+                                                     const int z, const int wave, const int lane) {
+    constexpr int NW = WQ * WP, NV = TQ * TP * 4, BQ = WQ * TQ * 32, BP = WP * TP * 32;
+    constexpr unsigned WG_BYTES = (unsigned)NW * NV * 64 * 16;
+    const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
+    const int tile = pt * nq + q0 / BQ, ntiles = nq * np;
+    const int S = a.splitk;
+    char* const base = reinterpret_cast<char*>(a.sk_ws);
+    const unsigned voff = (unsigned)(wave * NV * 64 + lane) * 16u;
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + ((size_t)z * ntiles + tile) * WG_BYTES, 0, WG_BYTES, 0x00020000);
+        static_for<0, TQ>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            static_for<0, TP>([&](auto Jc) {
+                constexpr int j = decltype(Jc)::value;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff + (unsigned)(((i * TP + j) * 4 + g) * 1024), 0, /*sc1*/ 16);
+                }
+            });
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // every wave's slab stores are out; the staging ring is dead
+    int* const tk = reinterpret_cast<int*>(smem);
+    if (threadIdx.x == 0) *tk = __hip_atomic_fetch_add(a.sk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *tk;
+    if (ticket != S - 1) return false;
+    static_for<0, TQ>([&](auto Ic) {
+        constexpr int i = decltype(Ic)::value;
+        static_for<0, TP>([&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            f32x4 sum[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sum[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int zz = 0; zz < S; ++zz) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + ((size_t)zz * ntiles + tile) * WG_BYTES, 0, WG_BYTES, 0x00020000);
+                u32x4_t r[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) r[g] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)(((i * TP + j) * 4 + g) * 1024), 0, /*sc1*/ 16);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sum[g] += __builtin_bit_cast(f32x4, r[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = sum[g][e];
+        });
+    });
+    if (threadIdx.x == 0) __hip_atomic_store(a.sk_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 template <int WQ, int WP, int TQ, int TP>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& a, f32x16 (&acc)[TQ][TP], h16* smem, const int q0, const int p0,
-                                               const int pt, const int z, const int wave, const int lane) {
+                                               const int pt, const int z_in, const int wave, const int lane) {
+    int z = z_in;
+    if (a.splitk > 1 && a.sk_cnt) {      // in-launch split-K: only the last-arriving slice of a tile runs the fused epilogue
+        if (!igemm_splitk_combine<WQ, WP, TQ, TP>(a, acc, smem, q0, pt, z, wave, lane)) return;
+        z = 0;
+    }
     const bool geglu = (a.act == LADI_ACT_GEGLU);
     const int Qout = geglu ? a.Q / 2 : a.Q;
     // workgroup-uniform: fp16 rows whose 8-channel chunks are whole and 16-byte aligned (ld % 8 == 0 with 16-byte aligned bases)

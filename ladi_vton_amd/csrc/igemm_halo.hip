@@ -41,14 +41,17 @@ constexpr int nx_sum(int t, int D, bool pf) {
     return n;
 }
 
-template <int TQ, int TP, int NXB, int NSTW, int WPN>
-__global__ __launch_bounds__(128 * WPN, 2) void igemm_halo_kernel(const IGemmArgs a) {
+// WMAX: widest image row the halo buffer is sized for (48: every level of the UNet at 512x384; 24: the 32x24 level and below, whose smaller
+// buffer leaves room for a third weight slot at two workgroups per CU).  WPN = 6: twelve waves (2 x 6), three per SIMD -- the 320x192 tile
+// that covers the 64x48 level (49 152 pixels x 320 channels at batch 8) with exactly 256 workgroups.
+template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48>
+__global__ __launch_bounds__(128 * WPN, (WPN == 6 ? 3 : 2)) void igemm_halo_kernel(const IGemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only (see igemm_kernel.h)
     constexpr int WQ = 2, WP = WPN, BK = 64, NT = 128 * WPN;    // 8 waves (2 x 4), or 4 waves (2 x 2) with two workgroups per CU
     constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
     constexpr int RPP = NT / 8;                                  // 64 tile rows per DMA pass of the workgroup
     constexpr int RQ = (BQ + RPP - 1) / RPP;                     // weight passes per tap
-    constexpr int XROWS = (BP + 2 * HALO_WMAX + 2 + RPP - 1) / RPP * RPP;   // rows of one halo-tile buffer (whole passes)
+    constexpr int XROWS = (BP + 2 * WMAX + 2 + RPP - 1) / RPP * RPP;   // rows of one halo-tile buffer (whole passes)
     constexpr int LX = XROWS / RPP;                              // halo passes per channel chunk
     constexpr int WSLOT = RQ * RPP * BK;                         // halves per weight slot (padded to whole passes)
     constexpr int XBUF = XROWS * BK;                             // halves per halo buffer
@@ -246,18 +249,18 @@ __global__ __launch_bounds__(128 * WPN, 2) void igemm_halo_kernel(const IGemmArg
 #endif
 }
 
-template <int TQ, int TP, int NXB, int NSTW, int WPN>
+template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48>
 int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
     constexpr int BQ = 64 * TQ, BP = 32 * WPN * TP, RPP = 16 * WPN;
-    constexpr int RQ = (BQ + RPP - 1) / RPP, XROWS = (BP + 2 * HALO_WMAX + 2 + RPP - 1) / RPP * RPP;
+    constexpr int RQ = (BQ + RPP - 1) / RPP, XROWS = (BP + 2 * WMAX + 2 + RPP - 1) / RPP * RPP;
     constexpr int SMEM = (NSTW * RQ * RPP * 64 + NXB * XROWS * 64) * (int)sizeof(h16) + 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget of one CU");
     static_assert(SMEM >= igemm_epilogue_lds_bytes<2, WPN, TQ>(), "epilogue patches must fit");
-    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups || a.Ws > HALO_WMAX || a.Ho != a.Hs || a.Wo != a.Ws) return -16;
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups || a.Ws > WMAX || a.Ho != a.Hs || a.Wo != a.Ws) return -16;
     if ((a.C0 % 64) || (a.C1 % 64) || (batch != 1 && a.splitk <= 1)) return -16;
     if ((size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 >= 0x7FFFFFFFull) return -16;   // 32-bit byte offsets from the tensor base
     static bool attr_set = false;
-    auto kfn = igemm_halo_kernel<TQ, TP, NXB, NSTW, WPN>;
+    auto kfn = igemm_halo_kernel<TQ, TP, NXB, NSTW, WPN, WMAX>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return -10;
         attr_set = true;
@@ -290,5 +293,9 @@ int ladi_launch_igemm_halo(const IGemmArgs& a, int tq, int tp, int nxb, int batc
     // 4-wave workgroups, TWO per CU (64-72 KB each): their barriers are independent, so one workgroup multiplies while the other waits
     if (tq == 2 && tp == 2 && nxb == 10) return launch_halo<2, 2, 1, 2, 2>(a, batch, st);  // 128x128
     if (tq == 2 && tp == 3 && nxb == 10) return launch_halo<2, 3, 1, 2, 2>(a, batch, st);  // 128x192
+    // round 4
+    if (tq == 2 && tp == 2 && nxb == 11) return launch_halo<2, 2, 1, 3, 2, 24>(a, batch, st);   // 128x128, 4 waves x 2 per CU, rows <= 24 pixels: 3 weight slots (72 KB)
+    if (tq == 2 && tp == 3 && nxb == 11) return launch_halo<2, 3, 1, 3, 2, 24>(a, batch, st);   // 128x192, same
+    if (tq == 5 && tp == 1 && nxb == 12) return launch_halo<5, 1, 1, 2, 6>(a, batch, st);       // 320x192, 12 waves (3 per SIMD), 144 KB
     return -7;
 }

@@ -9,8 +9,10 @@
 // *stats_row_px pixels per row (a multiple of 32 chosen with the tile shape; 0 = not produced, use ladi_launch_gn_partial)
 // ws / ws_bytes: caller-owned split-K slab (fp32 partial tiles) of at least ladi_igemm_splitk_ws_bytes(a, batch) bytes; null -> a
 // process-wide grow-only fallback buffer (never freed, so pointers baked into captured graphs stay valid)
+// sk_cnt: caller-owned arrival counters of the in-launch split-K combine (>= 1024 ints, zero-initialised once; every launch leaves them
+// zeroed) -- one buffer per stream that may run split-K launches concurrently; null -> a process-wide buffer (single-stream callers)
 int ladi_launch_igemm(const IGemmArgs& a, int batch, int cfg, hipStream_t st, int* stats_row_px = nullptr, float* ws = nullptr,
-                      size_t ws_bytes = 0);
+                      size_t ws_bytes = 0, int* sk_cnt = nullptr);
 // worst-case split-K slab for this problem over every admissible split configuration (0: split-K can never be chosen); depends on
 // the problem shape only, so a planning pass and the real pass allocate identically
 size_t ladi_igemm_splitk_ws_bytes(const IGemmArgs& a, int batch);
@@ -180,6 +182,7 @@ int ladi_launch_linear_f32(const float* x, int ldx, const float* W, const float*
 // ---- igemm per-launch timing hooks (HIP events on the launch stream); see igemm.hip
 void ladi_igemm_profile_enable(int on);
 void ladi_igemm_autotune(int on);   // measured tile-shape selection on first use of a problem shape (default on)
+void ladi_igemm_splitk_two_pass(int on);   // 1: split-K launches use the separate reduce pass (A/B switch; default: in-launch combine)
 int ladi_igemm_tuned_count();
 int ladi_igemm_num_cfgs();
 const char* ladi_igemm_cfg_symbol(int cfg);

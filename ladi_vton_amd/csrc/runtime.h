@@ -65,6 +65,7 @@ struct Ctx {
     size_t stats_off = 0, stats_cap = 0, stats_peak = 0;
     int err = 0;
     int* bad = nullptr;      // optional device flag: set by a GroupNorm whose input statistics are not finite (fp16 overflow upstream)
+    int* sk_cnt = nullptr;   // arrival counters of the in-launch split-K combine for THIS stream (1024 ints, zeroed once; kernels.h); null: process-wide
     bool dry() const { return ar->dry; }
     h16* alloc_h16(size_t elems) { return reinterpret_cast<h16*>(ar->alloc(elems * sizeof(h16))); }
     float* alloc_f32(size_t elems) { return reinterpret_cast<float*>(ar->alloc(elems * sizeof(float))); }
@@ -168,6 +169,7 @@ struct UNetLanes {
     hipEvent_t fork = nullptr, join[MAXG] = {};
     Arena arena[MAXG]; size_t peak[MAXG] = {};
     float* stats[MAXG] = {}; size_t stats_cap[MAXG] = {}, stats_peak[MAXG] = {};
+    int* sk_cnt[MAXG] = {};                 // per-lane split-K arrival counters (lanes run concurrently)
     static int pick(int n);                 // LADI_UNET_LANES (default 2), lowered until it divides n
     void configure(int n, int g = 0);       // g = 0: pick(n); creates the streams / events
     // x [n,h,w,64] -> eps [n,h,w,ld] (both caller-owned, contiguous in n).  dry: planning pass (records arena / statistics peaks, no
@@ -344,6 +346,7 @@ struct TryOn {
     Arena arena; float* stats = nullptr; size_t stats_cap = 0;
     DevPool pool;  // small persistent things
     StepTable* d_table = nullptr; int table_cap = 0; int* d_step = nullptr;
+    int* sk_cnt = nullptr;   // split-K arrival counters of this handle's stream (Ctx::sk_cnt)
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; unsigned long long graph_key = 0;
     UNetLanes lanes; int lanes_override = 0;   // sample-group lanes of the denoising loop (0 = LADI_UNET_LANES / default)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool ev_valid = false;

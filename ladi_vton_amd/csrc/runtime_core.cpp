@@ -198,7 +198,7 @@ void launch_conv_into(Ctx& c, IGemmArgs& a, Act& out, int cfg) {
     // captured graph only ever references memory covered by the graph key (arena base)
     const size_t wsb = ladi_igemm_splitk_ws_bytes(a, 1);
     float* ws = wsb ? c.alloc_f32(wsb / sizeof(float)) : nullptr;
-    if (!c.dry()) c.check(ladi_launch_igemm(a, 1, cfg, c.st, &px, ws, wsb), "igemm");
+    if (!c.dry()) c.check(ladi_launch_igemm(a, 1, cfg, c.st, &px, ws, wsb, c.sk_cnt), "igemm");
     out.st_px = px;
     if (!c.dry() && px == 0) out.st_part = nullptr;
 }

@@ -69,6 +69,7 @@ int TryOn::run(const TryOnInputs& in, void* images_out, int images_u8, float* la
     last_evals = evals;
 
     if (!d_step) d_step = reinterpret_cast<int*>(pool.alloc(256));
+    if (!sk_cnt) { sk_cnt = reinterpret_cast<int*>(pool.alloc(1024 * sizeof(int))); HIP_OK(hipMemset(sk_cnt, 0, 1024 * sizeof(int))); }
     if (evals > table_cap) { d_table = reinterpret_cast<StepTable*>(pool.alloc((size_t)evals * sizeof(StepTable))); table_cap = evals; }
     if (!ev[0]) for (auto& e : ev) HIP_OK(hipEventCreate(&e));
 
@@ -77,7 +78,7 @@ int TryOn::run(const TryOnInputs& in, void* images_out, int images_u8, float* la
         for (int pass = 0; pass < 2; ++pass) {
             arena.dry = (pass == 0);
             arena.off = 0;
-            Ctx c; c.st = st; c.ar = &arena; c.stats = stats; c.stats_cap = stats_cap;
+            Ctx c; c.st = st; c.ar = &arena; c.stats = stats; c.stats_cap = stats_cap; c.sk_cnt = sk_cnt;
             if (pass == 1) {
                 HIP_OK(hipMemcpyAsync(d_table, table.data(), (size_t)evals * sizeof(StepTable), hipMemcpyHostToDevice, st));
                 HIP_OK(hipMemsetAsync(d_step, 0, 2 * sizeof(int), st));    // evaluation index + the step kernel's arrival ticket

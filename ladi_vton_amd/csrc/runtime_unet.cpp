@@ -297,7 +297,7 @@ void UNetLanes::forward(UNet& u, hipStream_t main_st, bool dry, bool concurrent,
         hipStream_t sg = (par && g > 0) ? st[g] : main_st;
         if (par && g > 0) HIP_OK_L(hipStreamWaitEvent(sg, fork, 0));
         arena[g].dry = dry; arena[g].off = 0;
-        Ctx c; c.st = sg; c.ar = &arena[g]; c.stats = stats[g]; c.stats_cap = stats_cap[g];
+        Ctx c; c.st = sg; c.ar = &arena[g]; c.stats = stats[g]; c.stats_cap = stats_cap[g]; c.sk_cnt = sk_cnt[g];
         if (!dry && stats_cap[g]) HIP_OK_L(hipMemsetAsync(stats[g], 0, stats_cap[g] * sizeof(float), sg));
         Act xg = x; xg.n = ng; xg.p = x.p + (size_t)g * ng * x.h * x.w * x.ld;
         Act eg = eps; eg.n = ng; eg.p = eps.p + (size_t)g * ng * eps.h * eps.w * eps.ld; eg.st_part = nullptr; eg.st_px = 0;
@@ -309,6 +309,10 @@ void UNetLanes::forward(UNet& u, hipStream_t main_st, bool dry, bool concurrent,
 
 void UNetLanes::commit_plan() {
     for (int g = 0; g < G; ++g) {
+        if (!sk_cnt[g]) {
+            HIP_OK_L(hipMalloc(reinterpret_cast<void**>(&sk_cnt[g]), 1024 * sizeof(int)));
+            HIP_OK_L(hipMemset(sk_cnt[g], 0, 1024 * sizeof(int)));
+        }
         arena[g].reserve(peak[g] + 4096);
         if (stats_peak[g] > stats_cap[g]) {
             if (stats[g]) (void)hipFree(stats[g]);
@@ -331,6 +335,7 @@ unsigned long long UNetLanes::key() const {
 UNetLanes::~UNetLanes() {
     for (int i = 0; i < MAXG; ++i) {
         if (stats[i]) (void)hipFree(stats[i]);
+        if (sk_cnt[i]) (void)hipFree(sk_cnt[i]);
         if (join[i]) (void)hipEventDestroy(join[i]);
         if (st[i]) (void)hipStreamDestroy(st[i]);
     }

@@ -284,14 +284,15 @@ def test_igemm_tile_table_names_every_configuration(lib):
     """host side of the GEMM family: every tile configuration 1..ladi_igemm_cfg_count() maps to the kernel symbol rocprofv3 reports for it
     (bench.py groups its roofline by these names; profiles/r03_*), the table has the size the docs quote, and each kernel family is present"""
     n = lib.ladi_igemm_cfg_count()
-    assert n == 87
+    assert n == 92
     names = [lib.ladi_igemm_cfg_symbol_name(c).decode() for c in range(1, n + 1)]
     # the X-stationary configurations name their family only: the template arguments depend on the launch (K, LayerNorm, epilogue mode) and
     # are resolved per recorded launch by ladi_profile_igemm_symbols
     assert all(re.fullmatch(r"(igemm_kernel|igemm8_kernel|igemm_lc_kernel|igemm_halo_kernel)<[0-9a-z, ]+>|linear_xs_kernel", s) for s in names), names
     fam = {s.split("<")[0] for s in names}
     assert fam == {"igemm_kernel", "igemm8_kernel", "igemm_lc_kernel", "igemm_halo_kernel", "linear_xs_kernel"}, fam
-    assert names[84 - 1] == "igemm_halo_kernel<2, 2, 1, 2, 2>"        # the dominant symbol of the round-3 forward (profiles/r03_bench_default.json)
+    assert names[84 - 1] == "igemm_halo_kernel<2, 2, 1, 2, 2, 48>"    # the dominant symbol of the round-3 forward (profiles/r03_bench_default.json)
+    assert names[92 - 1] == "igemm_halo_kernel<5, 1, 1, 2, 6, 48>"    # round 4: the 12-wave 320x192 form (256 workgroups on the 64x48 level)
     assert not lib.ladi_igemm_cfg_symbol_name(0) and not lib.ladi_igemm_cfg_symbol_name(n + 1)   # out of range: empty, not a crash
 
 

@@ -128,15 +128,52 @@ def test_conv3x3_bias_res_temb(cin, cout, h, w, cfg):
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 34, 35, 36, 37, 38, 46, 49, 50, 51, 52, 53, 59, 60, 61, 69, 70, 71, 72, 73, 79, 80, 81, 82, 83, 86, 87])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 34, 35, 36, 37, 38, 46, 49, 50, 51, 52, 53, 59, 60, 61, 69, 70, 71, 72, 73, 79, 80, 81, 82, 83, 86, 87, 90, 91])
 def test_conv3x3_split_k(cfg):
-    """split-K variants (fp32 partial slices + reduce pass that applies the epilogue) on a few-tile / deep-K problem"""
+    """split-K variants on a few-tile / deep-K problem, in both forms: the in-launch combine (round 4: slices publish fp32 slabs with
+    write-through stores, the last-arriving slice of a tile sums them in slice order and runs the fused epilogue) and the separate reduce
+    pass of rounds 1-3.  Both against fp32 torch; the in-launch form must be bit-identical over repeated launches whichever slice arrives
+    last (race screen of the ticket hand-off)."""
+    lib = _lib.load()
     N, cin, cout, h, w = 2, 512, 192, 8, 6
     x, wt, b = _rand((N, cin, h, w), 60), _rand((cout, cin, 3, 3), 61, 1 / math.sqrt(9 * cin)), _rand((cout,), 62, 0.1)
     temb, res = _rand((cout,), 63), _rand((N, cout, h, w), 64)
     ref = F.silu(F.conv2d(x, wt, b, padding=1) + temb[None, :, None, None]) + res
-    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cout, bias=b, rowadd=temb, act="silu", res0=U.nhwc16(res), cfg=cfg)
+    X, Wp, R = U.nhwc16(x), U.pack_conv_weight(wt), U.nhwc16(res)
+    try:
+        lib.ladi_igemm_set_splitk_two_pass(1)
+        y2 = U.igemm(X, Wp, cout, bias=b, rowadd=temb, act="silu", res0=R, cfg=cfg)
+        assert U.rel_l2(U.to_nchw(y2), ref) < TOL
+    finally:
+        lib.ladi_igemm_set_splitk_two_pass(0)
+    y = U.igemm(X, Wp, cout, bias=b, rowadd=temb, act="silu", res0=R, cfg=cfg)
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
+    assert U.rel_l2(y.float().cpu(), y2.float().cpu()) < 1e-3
+    for _ in range(8):
+        assert torch.equal(U.igemm(X, Wp, cout, bias=b, rowadd=temb, act="silu", res0=R, cfg=cfg), y)
+
+
+@pytest.mark.parametrize("cfg", [87, 91, 13, 38])
+def test_split_k_in_launch_combine_at_the_8x6_level(cfg):
+    """the launch population the in-launch combine was built for: the 1280 -> 1280 3x3 convolution of the 8x6 level at the bench batch
+    (768 pixels: 60-120 tiles x 4-8 K slices spread over every XCD), residual epilogue, 30 launches back to back -- every output must equal
+    the first (a stale slab or a counter that was not re-armed shows up here) and the two-pass form within fp16 rounding"""
+    lib = _lib.load()
+    N, cin, cout, h, w = 16, 1280, 1280, 8, 6
+    x, wt, b = _rand((N, cin, h, w), 160), _rand((cout, cin, 3, 3), 161, 1 / math.sqrt(9 * cin)), _rand((cout,), 162, 0.1)
+    res = _rand((N, cout, h, w), 164)
+    X, Wp, R = U.nhwc16(x), U.pack_conv_weight(wt), U.nhwc16(res)
+    y = U.igemm(X, Wp, cout, bias=b, res0=R, cfg=cfg)
+    ref = F.conv2d(x[:2], wt, b, padding=1) + res[:2]
+    assert U.rel_l2(U.to_nchw(y[:2]), ref) < TOL
+    for _ in range(30):
+        assert torch.equal(U.igemm(X, Wp, cout, bias=b, res0=R, cfg=cfg), y)
+    try:
+        lib.ladi_igemm_set_splitk_two_pass(1)
+        y2 = U.igemm(X, Wp, cout, bias=b, res0=R, cfg=cfg)
+    finally:
+        lib.ladi_igemm_set_splitk_two_pass(0)
+    assert U.rel_l2(y.float().cpu(), y2.float().cpu()) < 1e-3
 
 
 @pytest.mark.parametrize("cfg", [32, 33] + NEW_IGEMM8 + [3, 7, 9, 39, 40, 42, 45, 47])
@@ -212,7 +249,10 @@ def test_fused_output_statistics(cfg):
     assert U.rel_l2(tot[:, 0], o.sum(0).cpu()) < 1e-4 and U.rel_l2(tot[:, 1], (o * o).sum(0).cpu()) < 1e-4
 
 
-@pytest.mark.parametrize("cfg", HALO + [79, 80, 86])
+HALO_W24 = [88, 89, 90, 91]     # halo buffer sized for rows of <= 24 pixels (third weight slot at two workgroups per CU)
+
+
+@pytest.mark.parametrize("cfg", HALO + [79, 80, 86] + HALO_W24 + [92])
 def test_conv3x3_halo_resident(cfg):
     """the halo-resident 3x3 convolution: the nine taps are applied when the B fragments are read from ONE staged pixel range, so what
     must be right is the tap shift / validity logic at image edges (left / right wrap-around, top / bottom rows, sample boundaries), the
@@ -220,7 +260,9 @@ def test_conv3x3_halo_resident(cfg):
     Repeated runs must be bit-identical (race screen of the counted waits)."""
     lib = _lib.load()
     for (N, c0, c1, cout, h, w_, act, seed) in ((3, 128, 0, 320, 20, 13, "none", 70), (2, 192, 64, 192, 9, 48, "silu", 74), (5, 64, 0, 96, 6, 6, "none", 78),
-                                               (1, 320, 0, 320, 64, 48, "none", 82)):
+                                               (1, 320, 0, 320, 64, 48, "none", 82), (2, 128, 128, 320, 32, 24, "silu", 86)):
+        if cfg in HALO_W24 and w_ > 24:
+            continue
         xa = _rand((N, c0, h, w_), seed)
         xb = _rand((N, c1, h, w_), seed + 1) if c1 else None
         wt, b = _rand((cout, c0 + c1, 3, 3), seed + 2, 1 / math.sqrt(9 * (c0 + c1))), _rand((cout,), seed + 3, 0.1)
@@ -243,6 +285,10 @@ def test_conv3x3_halo_resident(cfg):
     xw, w3 = _rand((1, 64, 4, 64), 92), _rand((64, 64, 3, 3), 93)
     with pytest.raises(AssertionError):
         U.igemm(U.nhwc16(xw), U.pack_conv_weight(w3), 64, cfg=cfg)
+    if cfg in HALO_W24:
+        xw = _rand((1, 64, 4, 32), 94)
+        with pytest.raises(AssertionError):
+            U.igemm(U.nhwc16(xw), U.pack_conv_weight(w3), 64, cfg=cfg)
 
 
 def test_conv3x3_stride2_pad1_and_asym():
