@@ -286,6 +286,8 @@ typedef struct {
     float* stats; int stats_groups; int splitk, tile_map /* both ignored: set by the launcher */;
     const void* ln_gamma; const void* ln_beta; float ln_eps; float bias_mul /* multiplier of bias, 0 = 1 */; void* ln_scratch;
     float* sk_ws; int* sk_cnt;   /* both ignored: set by the launcher (in-launch split-K combine) */
+    const float* gn_ss; int gn_hw; /* optional GroupNorm affine of the pixel operand: [n][C0][2] floats (scale, shift), pixels per sample
+                                      (multiple of 32); K = 320 / 640 projections without residual / GEGLU only */
     /* optional LayerNorm of the pixel operand (single source, 1x1): fused into the X-stationary linear kernel where the tuner finds that
        faster, else run as its own kernel into ln_scratch ([P][C0] fp16, caller-provided; null = only the fused form is admissible) */
 } ladi_igemm_desc;

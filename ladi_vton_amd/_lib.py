@@ -78,7 +78,7 @@ class IGemmDesc(Structure):
                 ("res0", c_void_p), ("res1", c_void_p), ("ldr0", c_int), ("ldr1", c_int), ("mask", c_void_p),
                 ("out", c_void_p), ("ldo", c_int), ("out_f32", c_int), ("stats", c_void_p), ("stats_groups", c_int), ("splitk", c_int), ("tile_map", c_int),
                 ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("bias_mul", c_float), ("ln_scratch", c_void_p),
-                ("sk_ws", c_void_p), ("sk_cnt", c_void_p)]
+                ("sk_ws", c_void_p), ("sk_cnt", c_void_p), ("gn_ss", c_void_p), ("gn_hw", c_int)]
 
 
 # every symbol include/ladi_native.h declares: name -> (restype, argtypes)

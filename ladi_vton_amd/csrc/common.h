@@ -115,4 +115,8 @@ struct IGemmArgs {
     // in-launch split-K combine (set by the launcher, igemm_common.h igemm_splitk_combine): fp32 slabs [splitk][tiles][workgroup image] and
     // the per-tile arrival counters (zero on entry, left zero); sk_cnt == nullptr with splitk > 1 = two-pass form (splitk_reduce_kernel)
     float* sk_ws; int* sk_cnt;
+    // optional GroupNorm affine of the pixel operand (no activation): x <- x * scale + shift per (sample, channel), rounded to fp16;
+    // gn_ss = [n][C0][2] floats (scale, shift) as gn_finalize writes them, gn_hw = pixels per sample (a multiple of 32).  Only the
+    // X-stationary linear kernel implements it (the launcher offers no other configuration when it is set)
+    const float* gn_ss; int gn_hw;
 };

@@ -402,6 +402,7 @@ static bool cfg_admissible(const IGemmArgs& a, int batch, int c, bool strict) {
         IGemmArgs t = a; t.stats = nullptr;
         return ladi_linear_xs_eligible(t, batch, ci.tp, ci.bq);
     }
+    if (a.gn_ss) return false;                                        // GroupNorm affine of the operand: X-stationary kernel only
     if (a.ln_gamma && !a.ln_scratch) return false;                    // no scratch: only the fused (X-stationary) form
     if (is_lc(ci.base) && (a.ups || batch != 1)) return false;        // loader / consumer kernel: no folded upsample, no batched launches
     if (is_halo(ci.base) && (!ladi_igemm_halo_eligible(a, batch) || ((ci.base == 88 || ci.base == 89) && a.Ws > 24))) return false;   // halo-resident kernel: 3x3 stride-1 convolutions on narrow images
@@ -444,7 +445,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     //      capture, every admissible configuration is timed with HIP events on the launch stream and the fastest is cached.
     //      Re-running a launch is idempotent (outputs never alias inputs in this library).
     // flags also carry the epilogue features that decide which kernels are admissible (residuals, fused statistics, other)
-    const int epi = (a.ln_gamma ? 128 : 0) | ((a.res0 || a.res1) ? 2 : 0) | (a.stats ? 8 : 0) |
+    const int epi = (a.gn_ss ? 256 : 0) | (a.ln_gamma ? 128 : 0) | ((a.res0 || a.res1) ? 2 : 0) | (a.stats ? 8 : 0) |
                     ((a.rowadd || a.mask || a.bias_per_pixel || a.out_f32 || a.out_scale != 1.f || (a.act != LADI_ACT_NONE && !geglu)) ? 64 : 0);
     TuneKey key{a.P, a.Q, a.K, a.C0, a.C1, a.Wo, (a.ksize << 8) | (a.stride << 4) | (a.ups << 2) | (geglu ? 1 : 0) | epi, batch};
     if (cfg == 0 && g_autotune) {
@@ -518,7 +519,11 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
             if (cost < best) { best = cost; cfg = c; }
         }
     }
+    if (cfg == 0 && a.gn_ss) {      // no measured selection and the cost model does not rank the X-stationary kernel: first eligible form
+        for (int c : {25, 26, 27, 23, 24}) if (cfg_admissible(a, batch, c, true)) { cfg = c; break; }
+    }
     if (cfg < 1 || cfg > NCFG) return -7;
+    if (a.gn_ss && kCfg[cfg].base != 23) return -17;
     if (a.ln_gamma && kCfg[cfg].base != 23) {   // LayerNorm as its own kernel into the caller's scratch (timed by the tuner as part of cfg)
         if (!a.ln_scratch || a.C1 || a.src1 || a.ksize != 1 || batch != 1) return -15;
         const int lrc = ladi_launch_layernorm(a.src0, a.ld0, a.ln_gamma, a.ln_beta, a.ln_eps, a.P, a.C0, a.ln_scratch, a.C0, st);

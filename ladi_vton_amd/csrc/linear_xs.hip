@@ -47,11 +47,14 @@ __device__ __forceinline__ void wait_vm_n(int n) {
 #undef XS_CASE
 
 // KH = K / 320, PB = 32-pixel blocks per wave, MODE 0: bias | 1: bias + residual (PB == 1) | 2: GEGLU (PB == 1; 32-row blocks of W
-// alternate u | g), LN: LayerNorm of the pixel panel in the prologue (a compile-time variant: a run-time branch around the rewrite
-// of the 160-VGPR panel makes the compiler keep both versions live and spill ~250 VGPRs).
+// alternate u | g), PRE: rewrite of the pixel panel in the prologue -- 1: LayerNorm (a compile-time variant: a run-time branch around
+// the rewrite of the 160-VGPR panel makes the compiler keep both versions live and spill ~250 VGPRs), 2: GroupNorm affine
+// x * scale[n][c] + shift[n][c] (round 4: the GroupNorm in front of proj_in has no activation, so its apply pass -- a full HBM round
+// trip of the block input -- folds into the consumer's register panel; statistics / finalize stay where they were).
 // grid = (P / (128*PB), channel slices); block = 4 waves.
-template <int KH, int PB, int MODE, bool LN>
+template <int KH, int PB, int MODE, int PRE>
 __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, int qb_per_slice) {
+    constexpr bool LN = (PRE == 1);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* ring = smem_raw;
     char* patch_base = smem_raw + XS_NST * XS_STAGE;
@@ -179,6 +182,36 @@ __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, in
             }
         }
     }
+    // ---- optional fused GroupNorm affine (a.gn_ss: [n][K][2] floats = (scale, shift) per sample and channel, written by gn_finalize):
+    //      a 32-pixel block lies inside one sample (the launcher requires gn_hw % 32 == 0); same arithmetic and rounding point (fp16
+    //      result) as gn_apply_kernel without activation
+    if constexpr (PRE == 2) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        auto pin = [](h16x8& v) {
+            i32x4 t = __builtin_bit_cast(i32x4, v);
+            asm volatile("" : "+v"(t));
+            v = __builtin_bit_cast(h16x8, t);
+        };
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const int n = (p0 + pb * 32) / a.gn_hw;
+            const float* ss = a.gn_ss + ((size_t)n * K + hh * 8) * 2;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                pin(xf[pb][ks]);
+                const float4* s4 = reinterpret_cast<const float4*>(ss + ks * 32);
+                h16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4 t = s4[e];
+                    o[2 * e] = (h16)((float)xf[pb][ks][2 * e] * t.x + t.y);
+                    o[2 * e + 1] = (h16)((float)xf[pb][ks][2 * e + 1] * t.z + t.w);
+                }
+                xf[pb][ks] = o;
+                pin(xf[pb][ks]);
+            }
+        }
+    }
     // ---- bias of this slice -> LDS, last in the prologue (its wait drains everything above, which stage 0 needs anyway)
     for (int i = tid; i < qb_per_slice * 32; i += 256) bias_s[i] = a.bias ? a.bias[qb0 * 32 + i] : (h16)0.f;
 
@@ -293,12 +326,12 @@ __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, in
     }
 }
 
-template <int KH, int PB, int MODE, bool LN>
+template <int KH, int PB, int MODE, int PRE>
 int launch_xs_ln(const IGemmArgs& a, int qs, hipStream_t st) {
     const int qb_per_slice = (a.Q / 32) / qs;
     const int smem = XS_NST * XS_STAGE + 4 * (MODE == 1 ? 2 * XS_RPATCH : XS_PATCH) + qb_per_slice * 32 * 2;
     if (smem > XS_SMEM_MAX) return -10;
-    auto kfn = linear_xs_kernel<KH, PB, MODE, LN>;
+    auto kfn = linear_xs_kernel<KH, PB, MODE, PRE>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, XS_SMEM_MAX) != hipSuccess) return -10;
@@ -311,7 +344,8 @@ int launch_xs_ln(const IGemmArgs& a, int qs, hipStream_t st) {
 
 template <int KH, int PB, int MODE>
 int launch_xs(const IGemmArgs& a, int qs, hipStream_t st) {
-    return a.ln_gamma ? launch_xs_ln<KH, PB, MODE, true>(a, qs, st) : launch_xs_ln<KH, PB, MODE, false>(a, qs, st);
+    if constexpr (MODE == 0) { if (a.gn_ss) return launch_xs_ln<KH, PB, MODE, 2>(a, qs, st); }
+    return a.ln_gamma ? launch_xs_ln<KH, PB, MODE, 1>(a, qs, st) : launch_xs_ln<KH, PB, MODE, 0>(a, qs, st);
 }
 
 }  // namespace
@@ -328,6 +362,7 @@ bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs) {
     if (geglu && res) return false;
     if (res && ((a.ldr0 % 8) || (size_t)a.P * a.ldr0 * 2 >= 0x7FFFFFFFull)) return false;
     if (a.out_scale != 1.f || a.splitk > 1 || (a.bias_mul != 0.f && a.bias_mul != 1.f)) return false;
+    if (a.gn_ss && (geglu || res || a.ln_gamma || a.gn_hw <= 0 || (a.gn_hw % 32))) return false;    // GroupNorm affine: plain projections only
     const int unit = geglu ? 64 : 32;
     if ((a.Q % unit) || ((a.Q / unit) % qs) || (a.P % (128 * pb))) return false;
     if ((size_t)a.Q * a.K * 2 >= 0x7FFFFFFFull) return false;
@@ -339,7 +374,7 @@ bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs) {
 void ladi_linear_xs_symbol(const IGemmArgs& a, int pb, char* out, int n) {
     const int kh = a.K == 320 ? 1 : 2, mode = a.act == LADI_ACT_GEGLU ? 2 : (a.res0 ? 1 : 0);
     const int pbb = (mode == 0 && a.K == 320 && pb == 2) ? 2 : 1;
-    snprintf(out, (size_t)n, "linear_xs_kernel<%d, %d, %d, %s>", kh, pbb, mode, a.ln_gamma ? "true" : "false");
+    snprintf(out, (size_t)n, "linear_xs_kernel<%d, %d, %d, %d>", kh, pbb, mode, (mode == 0 && a.gn_ss) ? 2 : (a.ln_gamma ? 1 : 0));
 }
 
 int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st) {

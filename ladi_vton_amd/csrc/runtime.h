@@ -93,6 +93,8 @@ struct ConvOpt {
     int cfg = 0;             // igemm tile config override
     bool stats = false;      // also produce per-channel partial statistics of the output (for a consuming GroupNorm)
     const DNorm* ln = nullptr; float ln_eps = 1e-5f;   // LayerNorm applied to the input first: fused into the kernel when it can be, else a launch
+    const float* gn_ss = nullptr;                      // GroupNorm affine of the input ([n][C][2] scale / shift from gn_scale_shift) applied
+                                                       // in the X-stationary kernel's prologue (see gn_fusable)
 };
 
 DConv load_conv(DevPool& pool, const WeightStore& ws, const std::string& prefix, int cin_expected = -1);      // 4-D or 2-D weight
@@ -106,6 +108,11 @@ Act new_act_with_stats(Ctx& c, int n, int h, int w, int cc);
 // launch an igemm whose output is `out` (pre-allocated), filling out.st_part / out.st_px when out.st_part != nullptr
 void launch_conv_into(Ctx& c, IGemmArgs& a, Act& out, int cfg = 0);
 Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups, float eps, int silu, const Act* add = nullptr);
+// statistics + finalize only: per-(sample, channel) scale / shift of GroupNorm(x | x2) as [n][C0 + C1][2] floats (what group_norm applies)
+float* gn_scale_shift(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups, float eps);
+// can a following 1x1 projection apply that affine in its own prologue instead of a gn_apply pass?  (X-stationary kernel: K = 320 / 640,
+// whole 128-pixel panels, 32-pixel blocks inside one sample); LADI_GN_FUSE=0 switches it off (A/B)
+bool gn_fusable(const Act& x, int cout);
 Act layer_norm(Ctx& c, const DNorm& nm, const Act& x, float eps);
 
 // ------------------------------------------------------------------------------------------------

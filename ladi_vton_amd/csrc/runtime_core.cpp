@@ -4,6 +4,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cmath>
+#include <cstdlib>
 
 namespace ladi {
 
@@ -228,6 +229,10 @@ Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& 
     if (o.res1) { a.res1 = o.res1->p; a.ldr1 = o.res1->ld; }
     a.mask = o.mask;
     a.out_f32 = 0;
+    if (o.gn_ss) {
+        if (x2 || o.ln) throw std::runtime_error("conv2d: GroupNorm affine needs a single, un-normalised source");
+        a.gn_ss = o.gn_ss; a.gn_hw = x.h * x.w;
+    }
     if (o.ln) {
         if (x2 || o.ln->c != C0) throw std::runtime_error("conv2d: LayerNorm input must be a single source of matching width");
         a.ln_gamma = o.ln->g; a.ln_beta = o.ln->b; a.ln_eps = o.ln_eps;
@@ -240,11 +245,10 @@ Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& 
 }
 
 // GroupNorm over the virtual concat (x | x2): partial statistics come from the producers' epilogues when available
-Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups, float eps, int silu, const Act* add) {
+float* gn_scale_shift(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups, float eps) {
     const int C0 = x.c, C1 = x2 ? x2->c : 0;
     if (C0 + C1 != nm.c) throw std::runtime_error("group_norm: channel mismatch");
     const int HW = x.h * x.w;
-    Act out = c.new_act(x.n, x.h, x.w, C0 + C1);
     float* ss = c.alloc_f32((size_t)x.n * (C0 + C1) * 2);
     const Act* srcs[2] = {&x, x2};
     const float* part[2] = {nullptr, nullptr};
@@ -263,11 +267,27 @@ Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups,
             part[i] = p; rps[i] = rows;
         }
     }
+    if (!c.dry())
+        c.check(ladi_launch_gn_finalize(part[0], C0, rps[0], part[1], C1, rps[1], x.n, HW, groups, nm.g, nm.b, eps, ss, c.st, c.bad), "gn_finalize");
+    return ss;
+}
+
+Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups, float eps, int silu, const Act* add) {
+    const int C0 = x.c, C1 = x2 ? x2->c : 0;
+    if (C0 + C1 != nm.c) throw std::runtime_error("group_norm: channel mismatch");
+    const int HW = x.h * x.w;
+    Act out = c.new_act(x.n, x.h, x.w, C0 + C1);
+    float* ss = gn_scale_shift(c, nm, x, x2, groups, eps);
     if (c.dry()) return out;
-    c.check(ladi_launch_gn_finalize(part[0], C0, rps[0], part[1], C1, rps[1], x.n, HW, groups, nm.g, nm.b, eps, ss, c.st, c.bad), "gn_finalize");
     c.check(ladi_launch_gn_apply(x.p, C0, x.ld, x2 ? x2->p : nullptr, C1, x2 ? x2->ld : 0, x.n, HW, ss, silu, add ? add->p : nullptr, out.p,
                                  c.st), "gn_apply");
     return out;
+}
+
+bool gn_fusable(const Act& x, int cout) {
+    static const bool on = [] { const char* e = getenv("LADI_GN_FUSE"); return !(e && e[0] == '0'); }();
+    const int HW = x.h * x.w;
+    return on && (x.c == 320 || x.c == 640) && x.ld == x.c && (HW % 32) == 0 && (x.pixels() % 128) == 0 && (cout % 32) == 0;
 }
 
 Act layer_norm(Ctx& c, const DNorm& nm, const Act& x, float eps) {

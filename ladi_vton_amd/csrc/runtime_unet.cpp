@@ -191,9 +191,16 @@ struct Fwd {
         const int n = x.n, T = x.h * x.w, C = b.C;
         Act out = new_act_with_stats(c, x.n, x.h, x.w, C);
         const size_t mk = c.ar->mark();
-        Act g = group_norm(c, b.gn, x, nullptr, u.cfg.groups, 1e-6f, 0);
-        Act tok = g; tok.h = T; tok.w = 1;  // tokens view [n][T][C]
+        // GroupNorm (no activation) -> proj_in: the normalisation's affine is applied to proj_in's register panel where the X-stationary
+        // kernel carries the projection (64x48 / 32x24 levels), else as its own pass
         ConvOpt op;
+        Act tok;
+        if (gn_fusable(x, b.proj_in.cout)) {
+            op.gn_ss = gn_scale_shift(c, b.gn, x, nullptr, u.cfg.groups, 1e-6f);
+            tok = x;
+        } else tok = group_norm(c, b.gn, x, nullptr, u.cfg.groups, 1e-6f, 0);
+        tok.h = T; tok.w = 1;  // tokens view [n][T][C]
+        tok.st_part = nullptr; tok.st_px = 0;
         Act t0 = conv2d(c, b.proj_in, tok, nullptr, op);
         ConvOpt oq; oq.ln = &b.ln1;                  // LayerNorm fused into the K = 320 / 640 projections (X-stationary kernel), else a launch
         Act qkv = conv2d(c, b.qkv, t0, nullptr, oq);

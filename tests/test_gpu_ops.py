@@ -802,3 +802,24 @@ def test_layernorm_without_scratch_needs_a_fusable_shape():
     x, w = _rand((1, 128, 16, 16), 115), _rand((128, 128), 116, 0.1)
     with pytest.raises(AssertionError):
         U.igemm(U.nhwc16(x), w.half().contiguous().to(U.dev()), 128, ksize=1, ln=(torch.ones(128), torch.zeros(128), 1e-5))
+
+
+@pytest.mark.parametrize("cin,hw,cfg", [(320, (64, 48), 0), (320, (64, 48), 23), (320, (64, 48), 25), (640, (32, 24), 0), (640, (32, 24), 26), (320, (8, 16), 27)])
+def test_linear_with_fused_group_norm_affine(cin, hw, cfg):
+    """GroupNorm (no activation) in front of proj_in folded into the X-stationary kernel's register panel: out = W (x * scale[n][c] +
+    shift[n][c]) + b with the affine rounded to fp16 like gn_apply_kernel; every configuration that is not the X-stationary kernel must
+    refuse the launch (no silent un-normalised product)"""
+    N = 2
+    h, w = hw
+    x = _rand((N, cin, h, w), 300)
+    wt, b = _rand((cin, cin, 1, 1), 301, 1 / math.sqrt(cin)), _rand((cin,), 302, 0.1)
+    g = torch.Generator().manual_seed(303)
+    scale = 0.5 + torch.rand((N, cin), generator=g)
+    shift = torch.randn((N, cin), generator=g) * 0.3
+    ss = torch.stack([scale, shift], dim=-1).contiguous().to(U.dev())
+    xn = (x.half().float() * scale[:, :, None, None] + shift[:, :, None, None]).half().float()
+    ref = F.conv2d(xn, wt.half().float(), b.half().float())
+    y = U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cin, ksize=1, bias=b, cfg=cfg, gn=(ss, h * w))
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL, (cin, hw, cfg)
+    with pytest.raises(AssertionError):
+        U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), cin, ksize=1, bias=b, cfg=7, gn=(ss, h * w))

@@ -38,7 +38,7 @@ def pack_conv_weight_cat(w, c0, c1):
 
 
 def igemm(x, w_packed, cout, ksize=3, stride=1, pad=None, ups=0, x2=None, bias=None, rowadd=None, act="none", res0=None, res1=None,
-          mask=None, out_f32=False, cfg=0, out_ld=None, ln=None):
+          mask=None, out_f32=False, cfg=0, out_ld=None, ln=None, gn=None):
     """x, x2: NHWC fp16 gpu tensors [N,H,W,C]; returns NHWC output [N,Ho,Wo,ldo]"""
     lib = _lib.load()
     N, H, W, C0 = x.shape
@@ -75,6 +75,9 @@ def igemm(x, w_packed, cout, ksize=3, stride=1, pad=None, ups=0, x2=None, bias=N
             scr = torch.empty((x.shape[0] * x.shape[1] * x.shape[2], x.shape[3]), dtype=torch.float16, device=x.device)
             keep.append(scr)
             d.ln_scratch = scr.data_ptr()
+    if gn is not None:       # (scale_shift [n][C0][2] fp32 gpu tensor, pixels per sample): GroupNorm affine of the pixel operand
+        keep.append(gn[0])
+        d.gn_ss, d.gn_hw = gn[0].data_ptr(), int(gn[1])
     d.out, d.ldo, d.out_f32 = out.data_ptr(), ldo, int(out_f32)
     rc = lib.ladi_op_igemm(ctypes.byref(d), 1, cfg, stream_ptr())
     assert rc == 0, "igemm rc=%d %s" % (rc, _lib.last_error())

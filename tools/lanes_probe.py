@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--pipe-lanes", default="1,2,4")
+    ap.add_argument("--lanes-list", default="1,2,4,8")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=384)
@@ -38,7 +39,7 @@ def main():
     unet.set_context(torch.cat([local["negative_prompt_embeds"], local["prompt_embeds"]]).contiguous())
     res = {"n": n, "h": h, "w": w}
     res["single_stream_ms"] = round(unet.time_forward(n, h, w, a.iters), 3)
-    for g in (1, 2, 4, 8):
+    for g in [int(v) for v in a.lanes_list.split(",") if v]:
         if n % g:
             continue
         for graph in (True, False):
