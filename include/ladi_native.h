@@ -137,6 +137,11 @@ void ladi_text_encoder_destroy(ladi_text_encoder* t);
  * argmax(input_ids) (:62-65), or NULL. */
 int ladi_text_encoder_forward(ladi_text_encoder* t, const int* input_ids_host, int B, int T, const void* word_embeddings_dev,
                               int num_vstar, void* out_hidden_dev, void* out_pooled_dev, void* stream);
+/* the same with input_ids already in DEVICE memory (the reference moves them there before the call, src/inference.py:291): the first '$'
+ * and the end-of-text row are found by a kernel and nothing crosses the host, so the call never synchronises.  No host-side validation in
+ * this form: ids are clamped to the vocabulary by the lookup and slots running past T are cut instead of raising. */
+int ladi_text_encoder_forward_dev(ladi_text_encoder* t, const int* input_ids_dev, int B, int T, const void* word_embeddings_dev,
+                                  int num_vstar, void* out_hidden_dev, void* out_pooled_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * CLIP ViT-H/14 vision encoder — replaces the transformers CLIPVisionModelWithProjection forward the reference calls at

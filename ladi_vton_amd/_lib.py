@@ -120,6 +120,7 @@ SIGNATURES = {
     "ladi_text_encoder_create": (_P, [POINTER(TextConfig), _P]),
     "ladi_text_encoder_destroy": (None, [_P]),
     "ladi_text_encoder_forward": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P, _P, _P]),
+    "ladi_text_encoder_forward_dev": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P, _P, _P]),
     "ladi_sched_timesteps": (c_int, [c_int, c_int, POINTER(c_int), c_int]),
     "ladi_sched_lms": (c_int, [c_int, _P, _P, _P, _P]),
     "ladi_sched_alphas_cumprod": (c_int, [POINTER(c_float)]),

@@ -407,7 +407,15 @@ int ladi_text_encoder_forward(ladi_text_encoder* t, const int* ids, int B, int T
     return guarded("ladi_text_encoder_forward", [&]() {
         if (!t || !ids || !out_hidden) throw std::runtime_error("null argument");
         if (wemb && nv <= 0) throw std::runtime_error("num_vstar must be positive when word embeddings are given");
-        return t->t.forward(ids, B, T, reinterpret_cast<const h16*>(wemb), nv, reinterpret_cast<h16*>(out_hidden), reinterpret_cast<h16*>(out_pooled), S(stream));
+        return t->t.forward(ids, 0, B, T, reinterpret_cast<const h16*>(wemb), nv, reinterpret_cast<h16*>(out_hidden), reinterpret_cast<h16*>(out_pooled), S(stream));
+    });
+}
+int ladi_text_encoder_forward_dev(ladi_text_encoder* t, const int* ids_dev, int B, int T, const void* wemb, int nv, void* out_hidden, void* out_pooled,
+                                  void* stream) {
+    return guarded("ladi_text_encoder_forward_dev", [&]() {
+        if (!t || !ids_dev || !out_hidden) throw std::runtime_error("null argument");
+        if (wemb && nv <= 0) throw std::runtime_error("num_vstar must be positive when word embeddings are given");
+        return t->t.forward(ids_dev, 1, B, T, reinterpret_cast<const h16*>(wemb), nv, reinterpret_cast<h16*>(out_hidden), reinterpret_cast<h16*>(out_pooled), S(stream));
     });
 }
 

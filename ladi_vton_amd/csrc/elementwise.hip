@@ -450,11 +450,11 @@ int ladi_launch_mask_mul(h16* feat, int C, int n_pix, const h16* mask, hipStream
 // unless first[b] <= t < first[b] + nv (first[b] >= 0: position of sentence b's first '$'), then word_emb[b][t - first[b]]; plus
 // the position embedding of t.  One block per row, 8 channels per thread.
 __global__ void text_embed_kernel(const int* __restrict__ ids, const int* __restrict__ first, int nv, const h16* __restrict__ tok,
-                                  const h16* __restrict__ pos, const h16* __restrict__ wemb, int T, int H, h16* __restrict__ out) {
+                                  const h16* __restrict__ pos, const h16* __restrict__ wemb, int T, int H, int vocab, h16* __restrict__ out) {
     const int row = blockIdx.x, b = row / T, t = row - b * T;
     const int f = first[b];
     const bool sp = wemb && f >= 0 && t >= f && t < f + nv;
-    const h16* src = sp ? wemb + ((size_t)b * nv + (t - f)) * H : tok + (size_t)ids[row] * H;
+    const h16* src = sp ? wemb + ((size_t)b * nv + (t - f)) * H : tok + (size_t)min(max(ids[row], 0), vocab - 1) * H;
     const h16* pp = pos + (size_t)t * H;
     for (int c = threadIdx.x * 8; c < H; c += blockDim.x * 8) {
         const h16x8 a = *reinterpret_cast<const h16x8*>(src + c);
@@ -464,6 +464,25 @@ __global__ void text_embed_kernel(const int* __restrict__ ids, const int* __rest
         for (int e = 0; e < 8; ++e) o[e] = (h16)((float)a[e] + (float)p8[e]);
         *reinterpret_cast<h16x8*>(out + (size_t)row * H + c) = o;
     }
+}
+// device side of encode_text_word_embedding.py:12-19,62-65 for ids that already live on the device: per sentence the position of the first
+// '$' (vstar) token (-1: none, or no pseudo-words given) and the row of the end-of-text token = first maximum of the ids (torch.argmax).
+// One wave per sentence; ids are clamped to the vocabulary by the caller's embedding lookup (no host round trip, hence no host error)
+__global__ void text_meta_kernel(const int* __restrict__ ids, int T, int vstar, int use_words, int* __restrict__ first, int* __restrict__ eot) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int f = 0x7fffffff, best = -1, arg = 0x7fffffff;
+    for (int t = lane; t < T; t += 64) {
+        const int id = ids[(size_t)b * T + t];
+        if (id == vstar && t < f) f = t;
+        if (id > best) { best = id; arg = t; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int f2 = __shfl_xor(f, o), b2 = __shfl_xor(best, o), a2 = __shfl_xor(arg, o);
+        f = min(f, f2);
+        if (b2 > best || (b2 == best && a2 < arg)) { best = b2; arg = a2; }
+    }
+    if (lane == 0) { first[b] = (use_words && f != 0x7fffffff) ? f : -1; eot[b] = b * T + arg; }
 }
 // dst[i][:] = src[rows[i]][:]  (pooled output: the eot row of every sentence)
 __global__ void gather_rows_kernel(const h16* __restrict__ src, const int* __restrict__ rows, int H, h16* __restrict__ dst) {
@@ -637,9 +656,13 @@ int ladi_launch_patchify(const void* px, int in_f32, int B, int S, int ps, int K
 }
 
 int ladi_launch_text_embed(const int* ids, const int* first, int nv, const h16* tok, const h16* pos, const h16* wemb, int B, int T,
-                           int H, h16* out, hipStream_t st) {
-    if (H % 8) return -1;
-    hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)(B * T)), dim3(128), 0, st, ids, first, nv, tok, pos, wemb, T, H, out);
+                           int H, int vocab, h16* out, hipStream_t st) {
+    if (H % 8 || vocab <= 0) return -1;
+    hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)(B * T)), dim3(128), 0, st, ids, first, nv, tok, pos, wemb, T, H, vocab, out);
+    return ok();
+}
+int ladi_launch_text_meta(const int* ids, int B, int T, int vstar, int use_words, int* first, int* eot, hipStream_t st) {
+    hipLaunchKernelGGL(text_meta_kernel, dim3((unsigned)B), dim3(64), 0, st, ids, T, vstar, use_words, first, eot);
     return ok();
 }
 int ladi_launch_gather_rows(const h16* src, const int* rows, int n, int H, h16* dst, hipStream_t st) {

@@ -445,7 +445,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     //      capture, every admissible configuration is timed with HIP events on the launch stream and the fastest is cached.
     //      Re-running a launch is idempotent (outputs never alias inputs in this library).
     // flags also carry the epilogue features that decide which kernels are admissible (residuals, fused statistics, other)
-    const int epi = (a.gn_ss ? 256 : 0) | (a.ln_gamma ? 128 : 0) | ((a.res0 || a.res1) ? 2 : 0) | (a.stats ? 8 : 0) |
+    const int epi = ((a.bias_mul != 0.f && a.bias_mul != 1.f) ? 512 : 0) | (a.gn_ss ? 256 : 0) | (a.ln_gamma ? 128 : 0) | ((a.res0 || a.res1) ? 2 : 0) | (a.stats ? 8 : 0) |
                     ((a.rowadd || a.mask || a.bias_per_pixel || a.out_f32 || a.out_scale != 1.f || (a.act != LADI_ACT_NONE && !geglu)) ? 64 : 0);
     TuneKey key{a.P, a.Q, a.K, a.C0, a.C1, a.Wo, (a.ksize << 8) | (a.stride << 4) | (a.ups << 2) | (geglu ? 1 : 0) | epi, batch};
     if (cfg == 0 && g_autotune) {

@@ -57,6 +57,10 @@ __global__ __launch_bounds__(128 * WPN, (WPN == 6 ? 3 : 2)) void igemm_halo_kern
     constexpr int XBUF = XROWS * BK;                             // halves per halo buffer
     constexpr int D = NSTW - 1;                                  // weight tiles issued ahead of the one being multiplied
     static_assert(NSTW >= 2 && NSTW <= 4, "weight ring depth");
+    // double halo buffer: the counted wait at taps 0..D-2 of a chunk lets the LAST halo passes of that chunk's own tile (issued at taps
+    // 9-D..7 of the previous chunk) stay in flight; that is safe only while those passes cover rows the first taps do not read -- the
+    // first D-1 taps read rows < BP + 2, the late passes start at row floor(LX (9 - D) / 8) * RPP (made explicit)
+    static_assert(NXB != 2 || ((LX * (9 - D)) / 8) * RPP >= BP + 2, "late halo passes would overlap the rows the first taps read");
     constexpr int ZOFF = NSTW * WSLOT + NXB * XBUF;              // the row of zeros (halves)
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -258,6 +262,13 @@ int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
     static_assert(SMEM >= igemm_epilogue_lds_bytes<2, WPN, TQ>(), "epilogue patches must fit");
     if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups || a.Ws > WMAX || a.Ho != a.Hs || a.Wo != a.Ws) return -16;
     if ((a.C0 % 64) || (a.C1 % 64) || (batch != 1 && a.splitk <= 1)) return -16;
+    if (NXB == 2 && a.splitk > 1) {
+        // a K slice that ENTERS a chunk at its last tap would never prefetch the next chunk's halo tile (the passes ride on taps 0..7):
+        // such a split is refused here rather than mis-computed (unreachable with the shipped split factors 2 and 4)
+        const int nk = a.K / 64, sps = (nk + a.splitk - 1) / a.splitk;
+        for (int z = 1; z < a.splitk; ++z)
+            if ((z * sps) % 9 == 8 && z * sps < nk) return -16;
+    }
     if ((size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 >= 0x7FFFFFFFull) return -16;   // 32-bit byte offsets from the tensor base
     static bool attr_set = false;
     auto kfn = igemm_halo_kernel<TQ, TP, NXB, NSTW, WPN, WMAX>;

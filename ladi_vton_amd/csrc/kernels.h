@@ -133,7 +133,9 @@ int ladi_launch_scale_h16(const h16* src, int lds_, h16* dst, int ldd, size_t n_
 // CLIP text embeddings + pseudo-word splice: ids [B][T] (device), first [B] = position of the sentence's first '$' or -1,
 // wemb fp16 [B][nv][H] or null; out [B][T][H] = (token | pseudo-word) embedding + position embedding
 int ladi_launch_text_embed(const int* ids, const int* first, int nv, const h16* tok, const h16* pos, const h16* wemb, int B, int T,
-                           int H, h16* out, hipStream_t st);
+                           int H, int vocab, h16* out, hipStream_t st);
+// per sentence: first[b] = position of the first `vstar` id (or -1; -1 too when use_words == 0), eot[b] = b*T + argmax(ids[b]) (first maximum)
+int ladi_launch_text_meta(const int* ids, int B, int T, int vstar, int use_words, int* first, int* eot, hipStream_t st);
 // TPS matching network helpers: per-channel affine (BatchNorm after ReLU), per-pixel L2 normalisation over channels, TPS grid
 int ladi_launch_channel_affine(const h16* x, int ldx, size_t n_pix, int C, const float* scale, const float* shift, h16* y, int ldy, hipStream_t st);
 int ladi_launch_l2norm_rows(const h16* x, int ldx, int rows, int C, h16* y, int ldy, hipStream_t st);

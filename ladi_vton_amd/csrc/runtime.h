@@ -178,7 +178,8 @@ struct UNetLanes {
     float* stats[MAXG] = {}; size_t stats_cap[MAXG] = {}, stats_peak[MAXG] = {};
     int* sk_cnt[MAXG] = {};                 // per-lane split-K arrival counters (lanes run concurrently)
     static int pick(int n);                 // LADI_UNET_LANES (default 2), lowered until it divides n
-    void configure(int n, int g = 0);       // g = 0: pick(n); creates the streams / events
+    void configure(int n, int g = 0);       // g = 0: pick(n); creates the streams / events; a changed lane count drops the old plan
+    void reset();                           // release every lane arena (streams / events / counters are kept)
     // x [n,h,w,64] -> eps [n,h,w,ld] (both caller-owned, contiguous in n).  dry: planning pass (records arena / statistics peaks, no
     // launches); concurrent = false runs the lanes one after the other on main_st (first evaluation: per-shape tile measurement wants
     // a quiet chip)
@@ -268,9 +269,12 @@ struct TextEncoder {
     std::vector<TextLayer> layers; DNorm final_ln;
     Arena arena;
     int* d_ids = nullptr; int ids_cap = 0;    // ids [B*T] | first [B] | eot row [B]
+    int* h_meta = nullptr; int h_cap = 0; hipEvent_t h_done = nullptr;   // pinned staging of the host-id path + "copy has been consumed" event
     void load(const TextCfg& c, const WeightStore& ws);
-    // ids_host [B][T]; word_emb fp16 [B][nv][hidden] (device) or null; out_hidden [B][T][hidden]; out_pooled [B][hidden] or null
-    int forward(const int* ids_host, int B, int T, const h16* word_emb, int nv, h16* out_hidden, h16* out_pooled, hipStream_t st);
+    // ids [B][T] int32 on the host (validated, errors like the reference) or on the device (ids_on_device: no host round trip, no
+    // validation -- out-of-range ids are clamped by the lookup, slots past the sequence end are cut); word_emb fp16 [B][nv][hidden]
+    // (device) or null; out_hidden [B][T][hidden]; out_pooled [B][hidden] or null.  Asynchronous on `st` in both forms.
+    int forward(const int* ids, int ids_on_device, int B, int T, const h16* word_emb, int nv, h16* out_hidden, h16* out_pooled, hipStream_t st);
     ~TextEncoder();
 };
 

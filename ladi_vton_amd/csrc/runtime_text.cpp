@@ -37,38 +37,58 @@ void TextEncoder::load(const TextCfg& c, const WeightStore& ws) {
 }
 
 TextEncoder::~TextEncoder() {
+    if (h_done) { (void)hipEventSynchronize(h_done); (void)hipEventDestroy(h_done); }
+    if (h_meta) (void)hipHostFree(h_meta);
     if (d_ids) (void)hipFree(d_ids);
 }
 
-int TextEncoder::forward(const int* ids_host, int B, int T, const h16* word_emb, int nv, h16* out_hidden, h16* out_pooled, hipStream_t st) {
+int TextEncoder::forward(const int* ids, int ids_on_device, int B, int T, const h16* word_emb, int nv, h16* out_hidden, h16* out_pooled, hipStream_t st) {
     if (B <= 0 || T <= 0 || T > cfg.max_pos) { set_error("text encoder: bad batch / sequence length"); return -1; }
     const int H = cfg.hidden;
-    // ---- host side of encode_text_word_embedding.py:12-19,62-65: first '$' per sentence, eot (= argmax id) row per sentence
-    std::vector<int> meta((size_t)B * T + 2 * B);
-    for (int b = 0; b < B; ++b) {
-        int first = -1, arg = 0;
-        for (int t = 0; t < T; ++t) {
-            const int id = ids_host[(size_t)b * T + t];
-            if (id < 0 || id >= cfg.vocab) { set_error("text encoder: token id out of range"); return -1; }
-            meta[(size_t)b * T + t] = id;
-            if (id == cfg.vstar_id && first < 0) first = t;
-            if (id > ids_host[(size_t)b * T + arg]) arg = t;     // first maximum, like torch.argmax
-        }
-        if (word_emb && first >= 0 && first + nv > T) {
-            set_error("text encoder: pseudo-word slots run past the sequence end (the reference raises IndexError here)");
-            return -1;
-        }
-        meta[(size_t)B * T + b] = word_emb ? first : -1;
-        meta[(size_t)B * T + B + b] = b * T + arg;
-    }
-    if ((int)meta.size() > ids_cap) {
+    const int nmeta = B * T + 2 * B;
+    if (nmeta > ids_cap) {
         if (d_ids) (void)hipFree(d_ids);
         d_ids = nullptr; ids_cap = 0;
-        if (hipMalloc(reinterpret_cast<void**>(&d_ids), meta.size() * sizeof(int)) != hipSuccess) { set_error("text encoder: hipMalloc"); return -1; }
-        ids_cap = (int)meta.size();
+        if (hipMalloc(reinterpret_cast<void**>(&d_ids), (size_t)nmeta * sizeof(int)) != hipSuccess) { set_error("text encoder: hipMalloc"); return -1; }
+        ids_cap = nmeta;
     }
-    if (hipMemcpyAsync(d_ids, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { set_error("text encoder: H2D"); return -1; }
-    if (hipStreamSynchronize(st) != hipSuccess) { set_error("text encoder: sync"); return -1; }   // `meta` is a pageable stack-owned buffer
+    if (ids_on_device) {
+        // ids already on the device (the reference moves them there before the call, inference.py:291): first '$' and end-of-text row
+        // are found by a kernel, nothing crosses the host
+        if (hipMemcpyAsync(d_ids, ids, (size_t)B * T * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("text encoder: D2D"); return -1; }
+        if (ladi_launch_text_meta(d_ids, B, T, cfg.vstar_id, word_emb ? 1 : 0, d_ids + (size_t)B * T, d_ids + (size_t)B * T + B, st)) { set_error("text encoder: meta"); return -1; }
+    } else {
+        // ---- host side of encode_text_word_embedding.py:12-19,62-65: first '$' per sentence, eot (= argmax id) row per sentence; staged
+        //      through a pinned buffer owned by the handle (re-used only after the previous call's copy has executed), so the call
+        //      does not synchronise the stream
+        if (!h_done && hipEventCreateWithFlags(&h_done, hipEventDisableTiming) != hipSuccess) { set_error("text encoder: event"); return -1; }
+        if (h_meta && hipEventSynchronize(h_done) != hipSuccess) { set_error("text encoder: sync"); return -1; }
+        if (nmeta > h_cap) {
+            if (h_meta) (void)hipHostFree(h_meta);
+            h_meta = nullptr; h_cap = 0;
+            if (hipHostMalloc(reinterpret_cast<void**>(&h_meta), (size_t)nmeta * sizeof(int), hipHostMallocDefault) != hipSuccess) { set_error("text encoder: hipHostMalloc"); return -1; }
+            h_cap = nmeta;
+        }
+        int* meta = h_meta;
+        for (int b = 0; b < B; ++b) {
+            int first = -1, arg = 0;
+            for (int t = 0; t < T; ++t) {
+                const int id = ids[(size_t)b * T + t];
+                if (id < 0 || id >= cfg.vocab) { set_error("text encoder: token id out of range"); return -1; }
+                meta[(size_t)b * T + t] = id;
+                if (id == cfg.vstar_id && first < 0) first = t;
+                if (id > ids[(size_t)b * T + arg]) arg = t;     // first maximum, like torch.argmax
+            }
+            if (word_emb && first >= 0 && first + nv > T) {
+                set_error("text encoder: pseudo-word slots run past the sequence end (the reference raises IndexError here)");
+                return -1;
+            }
+            meta[(size_t)B * T + b] = word_emb ? first : -1;
+            meta[(size_t)B * T + B + b] = b * T + arg;
+        }
+        if (hipMemcpyAsync(d_ids, meta, (size_t)nmeta * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { set_error("text encoder: H2D"); return -1; }
+        if (hipEventRecord(h_done, st) != hipSuccess) { set_error("text encoder: event record"); return -1; }
+    }
     const int* d_first = d_ids + (size_t)B * T;
     const int* d_eot = d_first + B;
 
@@ -79,7 +99,7 @@ int TextEncoder::forward(const int* ids_host, int B, int T, const h16* word_emb,
         Ctx c; c.st = st; c.ar = &arena;
         Act xa = c.new_act(B, T, 1, H), xb = c.new_act(B, T, 1, H);   // residual stream, ping-pong
         Act* cur = &xa; Act* nxt = &xb;
-        if (!c.dry()) c.check(ladi_launch_text_embed(d_ids, d_first, nv, tok, pos, word_emb, B, T, H, cur->p, st), "text_embed");
+        if (!c.dry()) c.check(ladi_launch_text_embed(d_ids, d_first, nv, tok, pos, word_emb, B, T, H, cfg.vocab, cur->p, st), "text_embed");
         for (const TextLayer& L : layers) {
             const size_t mk = c.ar->mark();
             Act a = layer_norm(c, L.ln1, *cur, cfg.ln_eps);

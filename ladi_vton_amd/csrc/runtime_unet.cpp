@@ -286,8 +286,18 @@ int UNetLanes::pick(int n) {
     return want;
 }
 
+void UNetLanes::reset() {
+    for (int i = 0; i < MAXG; ++i) {
+        if (st[i]) (void)hipStreamSynchronize(st[i]);
+        arena[i].~Arena(); new (&arena[i]) Arena();
+        peak[i] = 0;
+    }
+}
+
 void UNetLanes::configure(int n, int g) {
-    G = g > 0 ? g : pick(n);
+    const int want = g > 0 ? g : pick(n);
+    if (want != G && arena[0].cap) reset();     // another lane count than the one the arenas were planned for: start from a clean plan
+    G = want;
     if (G < 1 || G > MAXG || (n % G)) throw std::runtime_error("UNetLanes: the lane count must divide the sample count");
     if (!fork) HIP_OK_L(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     for (int i = 1; i < G; ++i) {

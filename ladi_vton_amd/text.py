@@ -52,7 +52,10 @@ class NativeCLIPTextEncoder(_Shim):
     def __call__(self, input_ids, word_embeddings=None, num_vstar=1, attention_mask=None):
         if attention_mask is not None:
             raise ValueError("attention_mask is not supported (the SD2 text encoder config has no use_attention_mask: tryon_pipe.py:244-247 passes None)")
-        ids = input_ids.reshape(-1, input_ids.shape[-1]).to(device="cpu", dtype=torch.int32).contiguous()
+        # ids on the host (tokenizer output): validated there, errors like the reference.  ids already on the device (the reference's
+        # `tokenized_text.to(device)`, inference.py:291): they stay there -- no device -> host copy, hence no synchronisation
+        on_dev = input_ids.is_cuda
+        ids = input_ids.reshape(-1, input_ids.shape[-1]).to(dtype=torch.int32).contiguous()
         B, T = ids.shape
         H = self.cfg["hidden"]
         we = None
@@ -63,15 +66,18 @@ class NativeCLIPTextEncoder(_Shim):
             if we.shape[1] < num_vstar or we.shape[2] != H:
                 raise ValueError("word_embeddings must be [B, >= num_vstar, %d]" % H)
             we = we[:, :num_vstar].to(device=self.device, dtype=torch.float16).contiguous()
-            vs = self.cfg.get("vstar_token_id", 259)
-            first = (ids == vs).int().argmax(dim=1)
-            has = (ids == vs).any(dim=1)
-            if bool((has & (first + num_vstar > T)).any()):
-                raise IndexError("pseudo-word slots run past the sequence end")      # what the reference's advanced indexing raises
+            if not on_dev:
+                vs = self.cfg.get("vstar_token_id", 259)
+                first = (ids == vs).int().argmax(dim=1)
+                has = (ids == vs).any(dim=1)
+                if bool((has & (first + num_vstar > T)).any()):
+                    raise IndexError("pseudo-word slots run past the sequence end")      # what the reference's advanced indexing raises
         hidden = torch.empty((B, T, H), dtype=torch.float16, device=self.device)
         pooled = torch.empty((B, H), dtype=torch.float16, device=self.device)
-        check(self.lib.ladi_text_encoder_forward(self.h, ctypes.c_void_p(ids.data_ptr()), B, T, ptr(we) if we is not None else None, num_vstar,
-                                                 ptr(hidden), ptr(pooled), stream_ptr()), "ladi_text_encoder_forward")
+        fwd = self.lib.ladi_text_encoder_forward_dev if on_dev else self.lib.ladi_text_encoder_forward
+        check(fwd(self.h, ctypes.c_void_p(ids.data_ptr()), B, T, ptr(we) if we is not None else None, num_vstar, ptr(hidden), ptr(pooled),
+                  stream_ptr()), "ladi_text_encoder_forward")
+        self._ids_keepalive = ids          # the host-id form copies from this buffer asynchronously
         return TextEncoderOutput(hidden, pooled)
 
 
