@@ -485,7 +485,7 @@ def main():
         try:
             probe = torch.zeros(2, dtype=torch.int64, device=dev)
             side = torch.cuda.Stream()
-            lanes_n = int(a.lanes) if a.lanes else int(os.environ.get("LADI_UNET_LANES", "2"))
+            lanes_n = int(a.lanes) if a.lanes else int(os.environ.get("LADI_UNET_LANES", "1"))
             while lanes_n > 1 and n % lanes_n:
                 lanes_n -= 1
             unet.time_forward_lanes(n, h, w, 1, lanes_n)                      # builds / tunes

@@ -186,6 +186,15 @@ __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, in
     //      a 32-pixel block lies inside one sample (the launcher requires gn_hw % 32 == 0); same arithmetic and rounding point (fp16
     //      result) as gn_apply_kernel without activation
     if constexpr (PRE == 2) {
+        // the (scale, shift) rows of this workgroup's sample: K x 2 floats, staged ONCE through LDS by all four waves (coalesced 16-byte
+        // loads) and read back as broadcasts -- per-lane global loads of the table cost twice the bytes of the panel itself
+        float* ss_s = reinterpret_cast<float*>(bias_s + qb_per_slice * 32);
+        {
+            const int n_wg = (int)(blockIdx.x * (128 * PB)) / a.gn_hw;        // the launcher guarantees one sample per workgroup panel
+            const float4* src = reinterpret_cast<const float4*>(a.gn_ss + (size_t)n_wg * K * 2);
+            for (int i = tid; i < K / 2; i += 256) reinterpret_cast<float4*>(ss_s)[i] = src[i];
+        }
+        __syncthreads();
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         auto pin = [](h16x8& v) {
             i32x4 t = __builtin_bit_cast(i32x4, v);
@@ -194,12 +203,10 @@ __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, in
         };
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-            const int n = (p0 + pb * 32) / a.gn_hw;
-            const float* ss = a.gn_ss + ((size_t)n * K + hh * 8) * 2;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 pin(xf[pb][ks]);
-                const float4* s4 = reinterpret_cast<const float4*>(ss + ks * 32);
+                const float4* s4 = reinterpret_cast<const float4*>(ss_s + (ks * 16 + hh * 8) * 2);
                 h16x8 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, in
 template <int KH, int PB, int MODE, int PRE>
 int launch_xs_ln(const IGemmArgs& a, int qs, hipStream_t st) {
     const int qb_per_slice = (a.Q / 32) / qs;
-    const int smem = XS_NST * XS_STAGE + 4 * (MODE == 1 ? 2 * XS_RPATCH : XS_PATCH) + qb_per_slice * 32 * 2;
+    const int smem = XS_NST * XS_STAGE + 4 * (MODE == 1 ? 2 * XS_RPATCH : XS_PATCH) + ((qb_per_slice * 32 * 2 + 15) & ~15) + (PRE == 2 ? KH * XS_KB * 8 : 0);
     if (smem > XS_SMEM_MAX) return -10;
     auto kfn = linear_xs_kernel<KH, PB, MODE, PRE>;
     static bool attr_set = false;
@@ -362,11 +369,12 @@ bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs) {
     if (geglu && res) return false;
     if (res && ((a.ldr0 % 8) || (size_t)a.P * a.ldr0 * 2 >= 0x7FFFFFFFull)) return false;
     if (a.out_scale != 1.f || a.splitk > 1 || (a.bias_mul != 0.f && a.bias_mul != 1.f)) return false;
-    if (a.gn_ss && (geglu || res || a.ln_gamma || a.gn_hw <= 0 || (a.gn_hw % 32))) return false;    // GroupNorm affine: plain projections only
+    // GroupNorm affine: plain projections only; a workgroup's pixel panel (128 * pb pixels) must lie inside one sample
+    if (a.gn_ss && (geglu || res || a.ln_gamma || a.gn_hw <= 0 || (a.gn_hw % (128 * pb)))) return false;
     const int unit = geglu ? 64 : 32;
     if ((a.Q % unit) || ((a.Q / unit) % qs) || (a.P % (128 * pb))) return false;
     if ((size_t)a.Q * a.K * 2 >= 0x7FFFFFFFull) return false;
-    if (XS_NST * XS_STAGE + 4 * (res ? 2 * XS_RPATCH : XS_PATCH) + (a.Q / qs) * 2 > XS_SMEM_MAX) return false;
+    if (XS_NST * XS_STAGE + 4 * (res ? 2 * XS_RPATCH : XS_PATCH) + (a.Q / qs) * 2 + 16 + (a.gn_ss ? a.K * 8 : 0) > XS_SMEM_MAX) return false;
     return true;
 }
 

@@ -287,7 +287,7 @@ Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups,
 bool gn_fusable(const Act& x, int cout) {
     static const bool on = [] { const char* e = getenv("LADI_GN_FUSE"); return !(e && e[0] == '0'); }();
     const int HW = x.h * x.w;
-    return on && (x.c == 320 || x.c == 640) && x.ld == x.c && (HW % 32) == 0 && (x.pixels() % 128) == 0 && (cout % 32) == 0;
+    return on && (x.c == 320 || x.c == 640) && x.ld == x.c && (HW % 128) == 0 && (cout % 32) == 0;
 }
 
 Act layer_norm(Ctx& c, const DNorm& nm, const Act& x, float eps) {
