@@ -791,3 +791,22 @@ def test_scheduler_exact_on_analytic_eps(steps):
             mid = t - ratio / 2.0                # orders 2, 3 and 4 all extrapolate a linear function to the step's midpoint
         assert torch.allclose(used, e + mid * e1, rtol=0, atol=1e-8), (i, t, float((used - (e + mid * e1)).abs().max()))
         x = xn
+
+
+def test_bench_hbm_kernels_reads_the_committed_profiles(monkeypatch):
+    """`roofline.hbm_kernels` / `roofline.traffic` of bench.py: GB/s = (2 x FETCH_SIZE + WRITE_SIZE) of the committed PMC passes / the average
+    duration of the committed kernel trace, accepted only for the library digest stamped into the files' first line"""
+    import bench
+    path = os.path.join(ROOT, "profiles", "%s_pmc_fetch_size.txt" % bench.PROFILE_ROUND)
+    dig = re.match(r"# lib_digest=(\w+)", open(path).readline()).group(1)
+    monkeypatch.setattr(bench, "lib_digest", lambda: dig)
+    h = bench.hbm_kernels()
+    ga = h["unet_forward"]["gn_apply_kernel"]
+    assert 500.0 < ga["GBps"] < 8000.0 and abs(ga["GBps"] - ga["MB_per_launch"] * 1e3 / ga["avg_us"]) < 1.0, ga
+    assert any("gn_apply" in k for k in h["vae_stages"]) and "source" in h
+    t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24>")
+    assert why is None and t["bytes_per_launch"] == t["fetch_bytes_x2"] + t["write_bytes"] > 10_000_000
+    monkeypatch.setattr(bench, "lib_digest", lambda: "another-build")
+    t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24>")
+    assert t is None and "stale" in why
+    assert "note" in bench.hbm_kernels()["unet_forward"]
