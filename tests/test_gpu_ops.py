@@ -153,7 +153,7 @@ def test_conv3x3_split_k(cfg):
         assert torch.equal(U.igemm(X, Wp, cout, bias=b, rowadd=temb, act="silu", res0=R, cfg=cfg), y)
 
 
-@pytest.mark.parametrize("cfg", [87, 91, 13, 38])
+@pytest.mark.parametrize("cfg", [87, 91, 83, 80, 13, 38])
 def test_split_k_in_launch_combine_at_the_8x6_level(cfg):
     """the launch population the in-launch combine was built for: the 1280 -> 1280 3x3 convolution of the 8x6 level at the bench batch
     (768 pixels: 60-120 tiles x 4-8 K slices spread over every XCD), residual epilogue, 30 launches back to back -- every output must equal
