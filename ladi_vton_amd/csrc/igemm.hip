@@ -112,7 +112,7 @@ struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; in
 // tile configurations (0 = choose: measured per shape when autotuning is on, else the cost model below).
 // {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K,
 //  K step, offered to the tuner}
-constexpr int NCFG = 92;
+constexpr int NCFG = 95;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1, 0, false},
     {128, 256, 2, true, 0.80f, 4, 1, 1, 32, true},   // 1: <2,2,2,4> BK32 NST3
@@ -220,11 +220,17 @@ const CfgInfo kCfg[NCFG + 1] = {
     {128, 128, 2, false, 0.00f, 2, 88, 2, 64, true},  // 90: cfg 88 + split-K 2
     {128, 128, 2, false, 0.00f, 2, 88, 4, 64, true},  // 91: cfg 88 + split-K 4
     {320, 192, 1, false, 0.00f, 1, 92, 1, 64, true},  // 92: halo 320x192, 12 waves
+    // 93..95 (round 4): X-stationary kernel with a two-slot weight ring = THREE workgroups per CU (K = 320: the 64x48 level)
+    {1, 128, 3, true, 0.00f, 1, 93, 1, 0, true},     // 93: 32 pixels / wave, 1 channel slice
+    {2, 128, 3, true, 0.00f, 1, 93, 1, 0, true},     // 94: 32 pixels / wave, 2 channel slices
+    {5, 128, 3, true, 0.00f, 1, 93, 1, 0, true},     // 95: 32 pixels / wave, 5 channel slices
 };
+inline bool is_xs(int base) { return base == 23 || base == 93; }
+inline int xs_nst(int base) { return base == 93 ? 2 : 3; }
 inline bool is_lc(int base) { return base >= 62 && base <= 68; }
 // kernels whose every wave reaches the shared epilogue can combine their K slices in the launch (igemm_common.h igemm_splitk_combine); the
 // loader / consumer kernel (its loader waves hold no accumulators) and the X-stationary kernel keep the two-pass form
-inline bool sk_inline_ok(int base) { return base != 23 && !is_lc(base); }
+inline bool sk_inline_ok(int base) { return base != 23 && base != 93 && !is_lc(base); }
 // arrival counters for launches that bring none (op-level entry points): zeroed once, every launch leaves them zeroed.  One stream at a
 // time -- the module graphs pass their own (launch_conv_into)
 int* g_sk_cnt = nullptr;
@@ -247,7 +253,7 @@ inline bool is_halo(int base) { return (base >= 74 && base <= 78) || base == 84 
 // rocprofv3's name of the kernel a configuration launches (bench.py groups its per-launch timings by symbol)
 std::string cfg_symbol(int c) {
     const int b = kCfg[c].base;
-    if (b == 23) return "linear_xs_kernel";
+    if (b == 23 || b == 93) return "linear_xs_kernel";
     switch (b) {
         case 32: return "igemm8_kernel<5, 2, 0>";
         case 33: return "igemm8_kernel<4, 2, 0>";
@@ -286,7 +292,8 @@ int launch_base(int cfg, const IGemmArgs& a, int batch, hipStream_t st) {
 #define X(base, WQ, WP, TQ, TP, BK, NST, OCC, ILV) case base: return ladi_igemm_launch_base_##base(a, batch, st);
         LADI_IGEMM_TILES_ALL(X)
 #undef X
-        case 23: return ladi_launch_linear_xs(a, kCfg[cfg].tp, kCfg[cfg].bq, st);
+        case 23: return ladi_launch_linear_xs(a, kCfg[cfg].tp, kCfg[cfg].bq, st, 3);
+        case 93: return ladi_launch_linear_xs(a, kCfg[cfg].tp, kCfg[cfg].bq, st, 2);
         case 32: return ladi_launch_igemm8(a, 5, 2, batch, st);
         case 33: return ladi_launch_igemm8(a, 4, 2, batch, st);
         case 54: return ladi_launch_igemm8(a, 2, 2, batch, st);
@@ -398,9 +405,9 @@ static bool splitk_admissible(const IGemmArgs& a, int c) {
 static bool cfg_admissible(const IGemmArgs& a, int batch, int c, bool strict) {
     const CfgInfo& ci = kCfg[c];
     const bool geglu = a.act == LADI_ACT_GEGLU;
-    if (ci.base == 23) {
+    if (is_xs(ci.base)) {
         IGemmArgs t = a; t.stats = nullptr;
-        return ladi_linear_xs_eligible(t, batch, ci.tp, ci.bq);
+        return ladi_linear_xs_eligible(t, batch, ci.tp, ci.bq, xs_nst(ci.base));
     }
     if (a.gn_ss) return false;                                        // GroupNorm affine of the operand: X-stationary kernel only
     if (a.ln_gamma && !a.ln_scratch) return false;                    // no scratch: only the fused (X-stationary) form
@@ -426,7 +433,7 @@ size_t ladi_igemm_splitk_ws_bytes(const IGemmArgs& a, int batch) {
     if (batch != 1 || a.act == LADI_ACT_GEGLU || a.out_f32 || a.bias_per_pixel || a.P <= 0 || a.Q <= 0) return 0;
     size_t need = 0;
     for (int c = 1; c <= NCFG; ++c)
-        if (kCfg[c].split > 1 && kCfg[c].base != 23 && splitk_admissible(a, c)) need = std::max(need, splitk_cfg_bytes(a, c));
+        if (kCfg[c].split > 1 && !is_xs(kCfg[c].base) && splitk_admissible(a, c)) need = std::max(need, splitk_cfg_bytes(a, c));
     return need;
 }
 
@@ -464,7 +471,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                                         for (int c = 1; c <= NCFG; ++c) {
                         if (!kCfg[c].tune || !cfg_admissible(a, batch, c, true)) continue;
                         // X-stationary kernel: no fused statistics there, charge the separate statistics pass the consumer then needs (~3 TB/s read)
-                        const float penalty_ms = (kCfg[c].base == 23 && a.stats) ? 3.f * (float)((double)a.P * a.Q * 2.0 / 3.0e9) : 0.f;
+                        const float penalty_ms = (is_xs(kCfg[c].base) && a.stats) ? 3.f * (float)((double)a.P * a.Q * 2.0 / 3.0e9) : 0.f;
                         if (ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes, sk_cnt) != 0) continue;   // warm-up (also sets function attributes)
                         (void)hipEventRecord(e0, st);
                         for (int r = 0; r < 3; ++r) (void)ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes, sk_cnt);
@@ -485,7 +492,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
                         for (size_t i = 0; i < cand.size() && i < 3 && cand[i].first <= lim; ++i) {
                             const int c = cand[i].second;
                             float pen = 0.f;
-                            if (kCfg[c].base == 23 && a.stats) pen = (float)((double)a.P * a.Q * 2.0 / 3.0e9);
+                            if (is_xs(kCfg[c].base) && a.stats) pen = (float)((double)a.P * a.Q * 2.0 / 3.0e9);
                             (void)hipEventRecord(e0, st);
                             for (int r = 0; r < 10; ++r) (void)ladi_launch_igemm(a, batch, c, st, nullptr, ws, ws_bytes, sk_cnt);
                             (void)hipEventRecord(e1, st);
@@ -508,7 +515,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         double best = 1e300;
         for (int c = 1; c <= NCFG; ++c) {
             const CfgInfo& ci = kCfg[c];
-            if (ci.base == 23 || ci.split > 1 || !(ci.eff > 0.f) || !cfg_admissible(a, batch, c, false)) continue;
+            if (is_xs(ci.base) || ci.split > 1 || !(ci.eff > 0.f) || !cfg_admissible(a, batch, c, false)) continue;
             const long long tiles = (long long)((a.Q + ci.bq - 1) / ci.bq) * ((a.P + ci.bp - 1) / ci.bp) * batch;
             const long long slots = 256LL * ci.blocks_per_cu;
             const double waves = (double)((tiles + slots - 1) / slots);
@@ -520,19 +527,19 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         }
     }
     if (cfg == 0 && a.gn_ss) {      // no measured selection and the cost model does not rank the X-stationary kernel: first eligible form
-        for (int c : {25, 26, 27, 23, 24}) if (cfg_admissible(a, batch, c, true)) { cfg = c; break; }
+        for (int c : {25, 26, 27, 23, 24, 93, 94, 95}) if (cfg_admissible(a, batch, c, true)) { cfg = c; break; }
     }
     if (cfg < 1 || cfg > NCFG) return -7;
-    if (a.gn_ss && kCfg[cfg].base != 23) return -17;
-    if (a.ln_gamma && kCfg[cfg].base != 23) {   // LayerNorm as its own kernel into the caller's scratch (timed by the tuner as part of cfg)
+    if (a.gn_ss && !is_xs(kCfg[cfg].base)) return -17;
+    if (a.ln_gamma && !is_xs(kCfg[cfg].base)) {   // LayerNorm as its own kernel into the caller's scratch (timed by the tuner as part of cfg)
         if (!a.ln_scratch || a.C1 || a.src1 || a.ksize != 1 || batch != 1) return -15;
         const int lrc = ladi_launch_layernorm(a.src0, a.ld0, a.ln_gamma, a.ln_beta, a.ln_eps, a.P, a.C0, a.ln_scratch, a.C0, st);
         if (lrc != 0) return -15;
         a.src0 = a.ln_scratch; a.ld0 = a.C0; a.ln_gamma = nullptr; a.ln_beta = nullptr;
     }
-    if (kCfg[cfg].base == 23) {   // X-stationary linear kernel: no fused statistics (the consumer falls back to ladi_launch_gn_partial)
+    if (is_xs(kCfg[cfg].base)) {   // X-stationary linear kernel: no fused statistics (the consumer falls back to ladi_launch_gn_partial)
         a.stats = nullptr;
-        if (!ladi_linear_xs_eligible(a, batch, kCfg[cfg].tp, kCfg[cfg].bq)) return -14;
+        if (!ladi_linear_xs_eligible(a, batch, kCfg[cfg].tp, kCfg[cfg].bq, xs_nst(kCfg[cfg].base))) return -14;
     }
     if (geglu && !kCfg[cfg].geglu_ok) return -8;
     if (kCfg[cfg].bk == 64 && ((a.C0 % 64) || (a.C1 % 64))) return -2;  // BK = 64 variants
@@ -562,7 +569,7 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     if (prof) {
         if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) return -12;
         rec.cfg = cfg; rec.P = a.P; rec.Q = a.Q; rec.K = a.K; rec.ks = a.ksize;
-        if (kCfg[cfg].base == 23) ladi_linear_xs_symbol(a, kCfg[cfg].tp, rec.sym, (int)sizeof(rec.sym));
+        if (is_xs(kCfg[cfg].base)) ladi_linear_xs_symbol(a, kCfg[cfg].tp, xs_nst(kCfg[cfg].base), rec.sym, (int)sizeof(rec.sym));
         else snprintf(rec.sym, sizeof(rec.sym), "%s", cfg_symbol(cfg).c_str());
         rec.flops = 2.0 * (double)a.P * (double)a.Q * (double)a.K * (double)batch;
         (void)hipEventRecord(rec.e0, st);

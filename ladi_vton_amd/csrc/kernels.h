@@ -29,9 +29,10 @@ bool ladi_igemm_halo_eligible(const IGemmArgs& a, int batch);
 int ladi_launch_igemm_halo(const IGemmArgs& a, int tq, int tp, int nxb, int batch, hipStream_t st);
 
 // ---- linear_xs.hip: X-stationary kernel for 1x1 layers with K = 320 / 640 (reached through ladi_launch_igemm cfg 23..27)
-bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs);
-int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st);
-void ladi_linear_xs_symbol(const IGemmArgs& a, int pb, char* out, int n);
+// nst: weight-ring depth (3: two workgroups per CU; 2: three workgroups per CU, K = 320 plain / GEGLU projections only)
+bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs, int nst = 3);
+int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st, int nst = 3);
+void ladi_linear_xs_symbol(const IGemmArgs& a, int pb, int nst, char* out, int n);
 
 // ---- norm.hip
 // GroupNorm in three stages (all atomics-free): per-channel partial statistics rows [rows][C][2] (written by the producing

@@ -27,12 +27,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int XS_KB = 320;                       // k extent of one weight stage
 constexpr int XS_STAGE = 32 * XS_KB * 2;         // bytes per stage: 32 rows x 640 B
-constexpr int XS_NST = 3;
 constexpr int XS_DMA = XS_STAGE / 16 / 256;      // 16-byte DMA pieces per thread per stage (5)
 constexpr int XS_PLD = 40;                       // halves per patch row (32 channels + 8 pad): 80 B, 16-byte aligned rows
 constexpr int XS_PATCH = 32 * XS_PLD * 2;        // bytes per wave patch (MODE 0 / 2)
 constexpr int XS_RPATCH = 32 * 64;               // bytes per residual landing / transpose buffer (MODE 1: dense swizzled rows, x2)
 constexpr int XS_SMEM_MAX = 80 * 1024;           // two workgroups per CU
+constexpr int XS_SMEM_MAX3 = 53 * 1024;          // three workgroups per CU (NST = 2 forms)
 
 #define XS_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
 // wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform; clamping down is conservative)
@@ -52,9 +52,14 @@ __device__ __forceinline__ void wait_vm_n(int n) {
 // x * scale[n][c] + shift[n][c] (round 4: the GroupNorm in front of proj_in has no activation, so its apply pass -- a full HBM round
 // trip of the block input -- folds into the consumer's register panel; statistics / finalize stay where they were).
 // grid = (P / (128*PB), channel slices); block = 4 waves.
-template <int KH, int PB, int MODE, int PRE>
-__global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, int qb_per_slice) {
+// NST: depth of the weight ring.  3 (two stages in flight) at two workgroups per CU is the round-1 form; NST = 2 (round 4) trades
+// the second in-flight stage for a THIRD workgroup per CU (52 KB of LDS instead of 72; the K = 320 kernels need 127-154 VGPRs, so the
+// registers allow three waves per SIMD): the other workgroups' MFMAs cover the shorter prefetch distance.
+template <int KH, int PB, int MODE, int PRE, int NST>
+__global__ __launch_bounds__(256, (NST == 2 ? 3 : 2)) void linear_xs_kernel(const IGemmArgs a, int qb_per_slice) {
     constexpr bool LN = (PRE == 1);
+    constexpr int XS_NST = NST;
+    static_assert(NST == 2 || NST == 3, "weight ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* ring = smem_raw;
     char* patch_base = smem_raw + XS_NST * XS_STAGE;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, in
     // m_next -> the stage after it; mr_cur / mr_next likewise for residual tiles
     int m_cur, m_next = 0, mr_cur = 0, mr_next = 0;
     issue_w(0); m_cur = vm_issued;
-    if (nstage > 1) { issue_w(1); m_next = vm_issued; }
+    if (NST == 3 && nstage > 1) { issue_w(1); m_next = vm_issued; }
     if (MODE == 1) { issue_res(ob0); mr_cur = vm_issued; }
     // ---- optional fused LayerNorm (a.ln_gamma): the lane pair (l31, hh = 0 / 1) holds one whole pixel row, so the statistics are two
     //      register passes and one cross-half shuffle each; same arithmetic and rounding point (fp16 result) as layernorm_kernel
@@ -250,9 +255,10 @@ __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, in
                 __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
             } else wait_vm_n(vm_issued - m_cur);      // stage s has landed (everything issued after it may stay in flight)
             asm volatile("s_barrier" ::: "memory");
-            m_cur = m_next;
+            if (NST == 3) m_cur = m_next;
             if (MODE == 1 && sub == 0 && ob + 1 < ob0 + nblk) { issue_res(ob + 1); mr_next = vm_issued; }
-            if (s + 2 < nstage) { issue_w(s + 2); m_next = vm_issued; }
+            if (NST == 3) { if (s + 2 < nstage) { issue_w(s + 2); m_next = vm_issued; } }
+            else if (s + 1 < nstage) { issue_w(s + 1); m_cur = vm_issued; }     // two slots: the one stage s - 1 just left is refilled
             const char* sW = ring + (s % XS_NST) * XS_STAGE;
 #pragma unroll
             for (int k16 = 0; k16 < XS_KB / 16; ++k16) {
@@ -333,15 +339,15 @@ __global__ __launch_bounds__(256, 2) void linear_xs_kernel(const IGemmArgs a, in
     }
 }
 
-template <int KH, int PB, int MODE, int PRE>
+template <int KH, int PB, int MODE, int PRE, int NST = 3>
 int launch_xs_ln(const IGemmArgs& a, int qs, hipStream_t st) {
     const int qb_per_slice = (a.Q / 32) / qs;
-    const int smem = XS_NST * XS_STAGE + 4 * (MODE == 1 ? 2 * XS_RPATCH : XS_PATCH) + ((qb_per_slice * 32 * 2 + 15) & ~15) + (PRE == 2 ? KH * XS_KB * 8 : 0);
-    if (smem > XS_SMEM_MAX) return -10;
-    auto kfn = linear_xs_kernel<KH, PB, MODE, PRE>;
+    const int smem = NST * XS_STAGE + 4 * (MODE == 1 ? 2 * XS_RPATCH : XS_PATCH) + ((qb_per_slice * 32 * 2 + 15) & ~15) + (PRE == 2 ? KH * XS_KB * 8 : 0);
+    if (smem > (NST == 2 ? XS_SMEM_MAX3 : XS_SMEM_MAX)) return -10;
+    auto kfn = linear_xs_kernel<KH, PB, MODE, PRE, NST>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, XS_SMEM_MAX) != hipSuccess) return -10;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, NST == 2 ? XS_SMEM_MAX3 : XS_SMEM_MAX) != hipSuccess) return -10;
         attr_set = true;
     }
     dim3 grid((unsigned)(a.P / (128 * PB)), (unsigned)qs);
@@ -349,16 +355,18 @@ int launch_xs_ln(const IGemmArgs& a, int qs, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 
-template <int KH, int PB, int MODE>
+template <int KH, int PB, int MODE, int NST = 3>
 int launch_xs(const IGemmArgs& a, int qs, hipStream_t st) {
-    if constexpr (MODE == 0) { if (a.gn_ss) return launch_xs_ln<KH, PB, MODE, 2>(a, qs, st); }
-    return a.ln_gamma ? launch_xs_ln<KH, PB, MODE, 1>(a, qs, st) : launch_xs_ln<KH, PB, MODE, 0>(a, qs, st);
+    if constexpr (MODE == 0) { if (a.gn_ss) return launch_xs_ln<KH, PB, MODE, 2, NST>(a, qs, st); }
+    return a.ln_gamma ? launch_xs_ln<KH, PB, MODE, 1, NST>(a, qs, st) : launch_xs_ln<KH, PB, MODE, 0, NST>(a, qs, st);
 }
 
 }  // namespace
 
 // pb: 32-pixel blocks per wave (1 or 2), qs: output-channel slices over gridDim.y
-bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs) {
+bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs, int nst) {
+    if (nst == 2 && (a.K != 320 || pb != 1 || a.res0)) return false;     // three-workgroup form: K = 320, 32 pixels per wave, plain / GEGLU
+    if (nst != 2 && nst != 3) return false;
     if (batch != 1 || a.ksize != 1 || a.stride != 1 || a.ups || a.C1 || a.src1 || a.K != a.C0) return false;
     const bool geglu = a.act == LADI_ACT_GEGLU;
     const bool res = a.res0 != nullptr;
@@ -374,19 +382,20 @@ bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs) {
     const int unit = geglu ? 64 : 32;
     if ((a.Q % unit) || ((a.Q / unit) % qs) || (a.P % (128 * pb))) return false;
     if ((size_t)a.Q * a.K * 2 >= 0x7FFFFFFFull) return false;
-    if (XS_NST * XS_STAGE + 4 * (res ? 2 * XS_RPATCH : XS_PATCH) + (a.Q / qs) * 2 + 16 + (a.gn_ss ? a.K * 8 : 0) > XS_SMEM_MAX) return false;
+    if (nst * XS_STAGE + 4 * (res ? 2 * XS_RPATCH : XS_PATCH) + (a.Q / qs) * 2 + 16 + (a.gn_ss ? a.K * 8 : 0) > (nst == 2 ? XS_SMEM_MAX3 : XS_SMEM_MAX)) return false;
     return true;
 }
 
 // the kernel symbol (as rocprofv3 prints it) ladi_launch_linear_xs launches for these arguments: <KH, PB, MODE, LN>
-void ladi_linear_xs_symbol(const IGemmArgs& a, int pb, char* out, int n) {
+void ladi_linear_xs_symbol(const IGemmArgs& a, int pb, int nst, char* out, int n) {
     const int kh = a.K == 320 ? 1 : 2, mode = a.act == LADI_ACT_GEGLU ? 2 : (a.res0 ? 1 : 0);
     const int pbb = (mode == 0 && a.K == 320 && pb == 2) ? 2 : 1;
-    snprintf(out, (size_t)n, "linear_xs_kernel<%d, %d, %d, %d>", kh, pbb, mode, (mode == 0 && a.gn_ss) ? 2 : (a.ln_gamma ? 1 : 0));
+    snprintf(out, (size_t)n, "linear_xs_kernel<%d, %d, %d, %d, %d>", kh, pbb, mode, (mode == 0 && a.gn_ss) ? 2 : (a.ln_gamma ? 1 : 0), nst);
 }
 
-int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st) {
-    if (!ladi_linear_xs_eligible(a, 1, pb, qs)) return -1;
+int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st, int nst) {
+    if (!ladi_linear_xs_eligible(a, 1, pb, qs, nst)) return -1;
+    if (nst == 2) return a.act == LADI_ACT_GEGLU ? launch_xs<1, 1, 2, 2>(a, qs, st) : launch_xs<1, 1, 0, 2>(a, qs, st);
     if (a.act == LADI_ACT_GEGLU) return a.K == 320 ? launch_xs<1, 1, 2>(a, qs, st) : launch_xs<2, 1, 2>(a, qs, st);
     if (a.res0) return a.K == 320 ? launch_xs<1, 1, 1>(a, qs, st) : launch_xs<2, 1, 1>(a, qs, st);
     if (a.K == 320) return pb == 2 ? launch_xs<1, 2, 0>(a, qs, st) : launch_xs<1, 1, 0>(a, qs, st);

@@ -40,7 +40,8 @@ def test_conv3x3_eight_wave_tiles(cfg):
 
 
 @pytest.mark.parametrize("cfg,C,Q,hw", [(23, 320, 320, (32, 16)), (24, 320, 960, (32, 24)), (25, 320, 320, (16, 24)), (26, 640, 640, (16, 16)),
-                                        (27, 640, 1920, (8, 16)), (25, 640, 96, (16, 8)), (27, 320, 160, (16, 16))])
+                                        (27, 640, 1920, (8, 16)), (25, 640, 96, (16, 8)), (27, 320, 160, (16, 16)),
+                                        (93, 320, 320, (16, 24)), (94, 320, 960, (32, 24)), (95, 320, 160, (16, 16))])   # 93-95: two-slot ring, three workgroups per CU
 def test_linear_x_stationary(cfg, C, Q, hw):
     """X-stationary linear kernel (pixel panel in registers, weights streamed): asymmetric weights catch any fragment /
     swizzle / channel-slice mix-up, random weights + bias check the arithmetic"""
@@ -74,7 +75,8 @@ def test_linear_x_stationary_residual(cfg, C, Q, hw):
     assert torch.equal(y, y_tiled)
 
 
-@pytest.mark.parametrize("cfg,C,Qh,T", [(25, 320, 256, 256), (26, 320, 1280, 128), (27, 640, 320, 384), (25, 640, 32, 128)])
+@pytest.mark.parametrize("cfg,C,Qh,T", [(25, 320, 256, 256), (26, 320, 1280, 128), (27, 640, 320, 384), (25, 640, 32, 128),
+                                        (93, 320, 256, 256), (94, 320, 1280, 128), (95, 320, 1280, 3072)])
 def test_linear_x_stationary_geglu(cfg, C, Qh, T):
     """GEGLU up-projection: interleaved u | g weight blocks, out = (u + bu) * gelu(g + bg)"""
     x, w, b = _rand((1, C, T, 1), 94), _rand((2 * Qh, C), 95, 1 / math.sqrt(C)), _rand((2 * Qh,), 96, 0.1)
@@ -779,6 +781,11 @@ def test_linear_with_fused_layernorm(C, Q, hw, act):
             bi[blk * 64 + i], bi[blk * 64 + 32 + i] = b[j], b[half + j]
         y = U.igemm(U.nhwc16(x), wi.half().contiguous().to(U.dev()), Q, ksize=1, bias=bi, act="geglu", ln=(gamma, beta, 1e-5))
         got = y.float().cpu().reshape(-1, half)
+        if C == 320:      # the three-workgroup form (cfg 95) with the fused LayerNorm, bit-equal over repeats (counted waits of the two-slot ring)
+            y3 = U.igemm(U.nhwc16(x), wi.half().contiguous().to(U.dev()), Q, ksize=1, bias=bi, act="geglu", ln=(gamma, beta, 1e-5), cfg=95)
+            assert U.rel_l2(y3.float().cpu().reshape(-1, half), ref) < TOL
+            for _ in range(5):
+                assert torch.equal(U.igemm(U.nhwc16(x), wi.half().contiguous().to(U.dev()), Q, ksize=1, bias=bi, act="geglu", ln=(gamma, beta, 1e-5), cfg=95), y3)
     else:
         ref = F.linear(xn, w, b)
         y = U.igemm(U.nhwc16(x), w.half().contiguous().to(U.dev()), Q, ksize=1, bias=b, ln=(gamma, beta, 1e-5))

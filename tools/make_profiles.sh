@@ -45,17 +45,17 @@ cp $O/r04_unet_forward_kernel_stats.txt $O/r04_pmc_fetch_size.txt $O/r04_pmc_wri
 timeout 1200 python bench.py --steps 10 --warmup 3 > $O/r04_bench_default.json 2> $O/r04_bench_default.err
 timeout 300 python bench.py --config 2 --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > $O/r04_bench_config2.json 2>/dev/null
 timeout 300 python bench.py --scheduler ddim --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $O/r04_bench_ddim.json 2>/dev/null
-timeout 300 python bench.py --scheduler lms --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $O/r04_bench_lms.json 2>/dev/null
+[ -z "${LADI_PROFILE_QUICK:-}" ] && timeout 300 python bench.py --scheduler lms --no-cpu-baseline --no-roofline --steps 3 --warmup 1 > $O/r04_bench_lms.json 2>/dev/null
 timeout 400 python bench.py --config 4 --no-cpu-baseline --no-roofline --steps 1 --warmup 1 > $O/r04_bench_config4.json 2>/dev/null
 timeout 300 python bench.py --roofline-only --no-cpu-baseline > $O/r04_bench_roofline_only.json 2>/dev/null
-timeout 400 python bench.py --config 2 --roofline-only --no-cpu-baseline > $O/r04_bench_config2_roofline_only.json 2>/dev/null
-timeout 400 python bench.py --config 4 --roofline-only --no-cpu-baseline > $O/r04_bench_config4_roofline_only.json 2>/dev/null
+[ -z "${LADI_PROFILE_QUICK:-}" ] && timeout 400 python bench.py --config 2 --roofline-only --no-cpu-baseline > $O/r04_bench_config2_roofline_only.json 2>/dev/null
+[ -z "${LADI_PROFILE_QUICK:-}" ] && timeout 400 python bench.py --config 4 --roofline-only --no-cpu-baseline > $O/r04_bench_config4_roofline_only.json 2>/dev/null
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/ktb -- python $R/bench.py --no-cpu-baseline --no-roofline --no-tail --steps 1 --warmup 1 > /dev/null 2>&1
 cd $R
 python tools/rocpd_stats.py $(find $O/ktb -name "*.db" | head -1) $O/r04_bench_kernel_stats.txt > /dev/null; rm -rf $O/ktb
 timeout 300 python $R/tools/bench_attn.py > $O/r04_attn_bench.txt 2>/dev/null
-timeout 500 python tools/bench_shapes.py --n 16 --iters 10 --json $O/r04_shapes_n16.json > $O/r04_shapes_n16.txt 2>&1
+timeout 500 python tools/bench_shapes.py --n 16 --iters ${LADI_SHAPES_ITERS:-10} --json $O/r04_shapes_n16.json > $O/r04_shapes_n16.txt 2>&1
 head -c 500 $O/r04_bench_default.json; echo; tail -2 $O/r04_bench_default.err
 head -14 $O/r04_unet_forward_kernel_stats.txt | cut -c1-150; head -6 $O/r04_pmc_mfma_busy.txt | cut -c1-200
 python - <<'PY'
@@ -65,3 +65,6 @@ r = d["roofline"]
 print({k: r.get(k) for k in ("kernel", "achieved", "frac", "traffic", "unet_forward_ms", "igemm_all_tflops", "clock")})
 print(json.dumps(r.get("hbm_kernels"))[:1500])
 PY
+
+# quick end-to-end parity of the final binary against the committed oracle outputs (the full suite is tools/final_check.sh)
+timeout 600 python -m pytest tests/test_gpu_e2e_golden.py -x -q -k "unet_forward_at or baseline_batch8 or config2_chain" 2>&1 | tail -3
