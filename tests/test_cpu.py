@@ -805,7 +805,7 @@ def test_bench_hbm_kernels_reads_the_committed_profiles(monkeypatch):
     assert 500.0 < ga["GBps"] < 8000.0 and abs(ga["GBps"] - ga["MB_per_launch"] * 1e3 / ga["avg_us"]) < 1.0, ga
     assert any("gn_apply" in k for k in h["vae_stages"]) and "source" in h
     t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24>")
-    assert why is None and t["bytes_per_launch"] == t["fetch_bytes_x2"] + t["write_bytes"] > 10_000_000
+    assert why is None and abs(t["bytes_per_launch"] - (t["fetch_bytes_x2"] + t["write_bytes"])) <= 2 and t["bytes_per_launch"] > 10_000_000   # each term is rounded on its own
     monkeypatch.setattr(bench, "lib_digest", lambda: "another-build")
     t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24>")
     assert t is None and "stale" in why
