@@ -33,7 +33,10 @@ constexpr int SLOT = D_DMA * 4096;
 constexpr int PLD = 40;                          // halves per patch row (32 channels + 8 pad)
 constexpr int PATCH = 32 * PLD * 2;
 constexpr int BIAS1 = 2 * HID * 2;               // the up-projection's bias vector (5 KB)
-constexpr int SMEM = 2 * SLOT + BIAS1 + 4 * PATCH;
+constexpr int NST = 6;                           // ring depth: at ONE workgroup per CU nobody else covers a stage's round trip -- a stage is
+                                                 // consumed in ~0.3 us (20 MFMAs), so five stages (~110 KB) have to be in flight
+constexpr int NSTAGE = 3 * NB;
+constexpr int SMEM = NST * SLOT + BIAS1 + 4 * PATCH;
 
 struct Args {
     const h16* x; const h16* ln_g; const h16* ln_b; float ln_eps;
@@ -45,11 +48,15 @@ struct Args {
 };
 
 #define VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+// wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform; clamping down is conservative; the
+// counter has 6 bits)
 __device__ __forceinline__ void wait_vm_n(int n) {
-    switch (n < 24 ? n : 24) {
+    switch (n < 48 ? n : 48) {
         VM_CASE(1) VM_CASE(2) VM_CASE(3) VM_CASE(4) VM_CASE(5) VM_CASE(6) VM_CASE(7) VM_CASE(8) VM_CASE(9) VM_CASE(10) VM_CASE(11) VM_CASE(12)
         VM_CASE(13) VM_CASE(14) VM_CASE(15) VM_CASE(16) VM_CASE(17) VM_CASE(18) VM_CASE(19) VM_CASE(20) VM_CASE(21) VM_CASE(22) VM_CASE(23)
-        VM_CASE(24)
+        VM_CASE(24) VM_CASE(25) VM_CASE(26) VM_CASE(27) VM_CASE(28) VM_CASE(29) VM_CASE(30) VM_CASE(31) VM_CASE(32) VM_CASE(33) VM_CASE(34)
+        VM_CASE(35) VM_CASE(36) VM_CASE(37) VM_CASE(38) VM_CASE(39) VM_CASE(40) VM_CASE(41) VM_CASE(42) VM_CASE(43) VM_CASE(44) VM_CASE(45)
+        VM_CASE(46) VM_CASE(47) VM_CASE(48)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -77,8 +84,8 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf
 __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
-    h16* bias_s = reinterpret_cast<h16*>(smem + 2 * SLOT);       // [2 HID]
-    char* patch_base = smem + 2 * SLOT + BIAS1;
+    h16* bias_s = reinterpret_cast<h16*>(smem + NST * SLOT);     // [2 HID]
+    char* patch_base = smem + NST * SLOT + BIAS1;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,7 +105,8 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const Args a) {
     int vm_issued = 0;                           // running count of this wave's VMEM operations (wave-uniform)
     // stage (hb, kind): kind 0 / 1 = the u / g rows of hidden block hb (32-row block 2 hb + kind of the packed W1; swizzled, 5 pieces per
     // thread); kind 2 = the packed W2 slice of hidden block hb (linear, 6 rounds)
-    auto issue_stage = [&](int hb, int kind, int slot) {
+    auto issue_stage = [&](int t, int slot) {    // stage t = (hidden block t / 3, kind t % 3)
+        const int hb = t / 3, kind = t - 3 * hb;
         char* dst = ring + slot * SLOT + wave * 1024;
         if (kind < 2) {
 #pragma unroll
@@ -121,8 +129,11 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const Args a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const h16x8*>(xp + ks * 16);
     }
-    int m_w;                                     // value of vm_issued right after the awaited weight stage was issued
-    issue_stage(0, 0, 0); m_w = vm_issued;
+    // marks: mk[i] = value of vm_issued right after stage (current + i) was issued; the ring keeps NST - 1 stages in flight
+    int mk[NST - 1];
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) { issue_stage(i, i); mk[i] = vm_issued; }
+    int rd_slot = 0, wr_slot = NST - 1;          // slot of the stage being multiplied / of the next stage to issue
     // ---- LayerNorm of the panel (same arithmetic and rounding point as layernorm_kernel / linear_xs PRE = 1)
     {
         typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -196,12 +207,15 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const Args a) {
         static_for<0, 3>([&](auto Kc) {
             constexpr int kind = decltype(Kc)::value;
             const int s = 3 * hb + kind;
-            if (s == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): panel, LayerNorm vectors, bias, stage 0
-            else wait_vm_n(vm_issued - m_w);                    // stage s has landed
+            if (s == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): panel, LayerNorm vectors, bias, the prologue's stages
+            else wait_vm_n(vm_issued - mk[0]);                  // stage s has landed; the NST - 2 stages behind it may stay in flight
             asm volatile("s_barrier" ::: "memory");
-            if (kind < 2) { issue_stage(hb, kind + 1, (s + 1) & 1); m_w = vm_issued; }     // the slot stage s - 1 just left
-            else if (hb + 1 < NB) { issue_stage(hb + 1, 0, (s + 1) & 1); m_w = vm_issued; }
-            const char* sW = ring + (s & 1) * SLOT;
+#pragma unroll
+            for (int i = 0; i + 1 < NST - 1; ++i) mk[i] = mk[i + 1];
+            if (s + NST - 1 < NSTAGE) { issue_stage(s + NST - 1, wr_slot); mk[NST - 2] = vm_issued; }    // into the slot stage s - 1 just left
+            wr_slot = (wr_slot + 1 == NST) ? 0 : wr_slot + 1;
+            const char* sW = ring + rd_slot * SLOT;
+            rd_slot = (rd_slot + 1 == NST) ? 0 : rd_slot + 1;
             if constexpr (kind < 2) {
 #pragma unroll
                 for (int k16 = 0; k16 < KS; ++k16) {

@@ -35,7 +35,10 @@ constexpr int O_DMA = 6;                         // ... lands in six 4 KB DMA ro
 constexpr int SLOT = O_DMA * 4096;               // ring slot: the larger of the two stage kinds
 constexpr int PLD = 40;                          // halves per patch row (32 channels + 8 pad)
 constexpr int PATCH = 32 * PLD * 2;
-constexpr int SMEM = 2 * SLOT + 4 * KVBUF + 4 * PATCH;
+constexpr int NST = 4;                           // ring depth: ONE workgroup per CU, nobody else covers a stage's round trip (a stage is consumed
+                                                 // in ~0.3 us): three stages (~70 KB) in flight; the K / V^T tiles are single-buffered
+constexpr int NSTAGE = 4 * HEADS;
+constexpr int SMEM = NST * SLOT + 2 * KVBUF + 4 * PATCH;
 
 struct Args {
     const h16* x; const h16* ln_g; const h16* ln_b; float ln_eps;
@@ -48,11 +51,15 @@ struct Args {
 };
 
 #define VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+// wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform; clamping down is conservative; the
+// counter has 6 bits)
 __device__ __forceinline__ void wait_vm_n(int n) {
-    switch (n < 24 ? n : 24) {
+    switch (n < 48 ? n : 48) {
         VM_CASE(1) VM_CASE(2) VM_CASE(3) VM_CASE(4) VM_CASE(5) VM_CASE(6) VM_CASE(7) VM_CASE(8) VM_CASE(9) VM_CASE(10) VM_CASE(11) VM_CASE(12)
         VM_CASE(13) VM_CASE(14) VM_CASE(15) VM_CASE(16) VM_CASE(17) VM_CASE(18) VM_CASE(19) VM_CASE(20) VM_CASE(21) VM_CASE(22) VM_CASE(23)
-        VM_CASE(24)
+        VM_CASE(24) VM_CASE(25) VM_CASE(26) VM_CASE(27) VM_CASE(28) VM_CASE(29) VM_CASE(30) VM_CASE(31) VM_CASE(32) VM_CASE(33) VM_CASE(34)
+        VM_CASE(35) VM_CASE(36) VM_CASE(37) VM_CASE(38) VM_CASE(39) VM_CASE(40) VM_CASE(41) VM_CASE(42) VM_CASE(43) VM_CASE(44) VM_CASE(45)
+        VM_CASE(46) VM_CASE(47) VM_CASE(48)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -66,9 +73,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 __global__ __launch_bounds__(256, 1) void xattn_full_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
-    char* kbuf = smem + 2 * SLOT;                // [2][KVBUF]
-    char* vbuf = kbuf + 2 * KVBUF;               // [2][KVBUF]
-    char* patch_base = vbuf + 2 * KVBUF;
+    char* kbuf = smem + NST * SLOT;              // [KVBUF]
+    char* vbuf = kbuf + KVBUF;                   // [KVBUF]
+    char* patch_base = vbuf + KVBUF;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,7 +96,8 @@ __global__ __launch_bounds__(256, 1) void xattn_full_kernel(const Args a) {
     int vm_issued = 0;                           // running count of this wave's VMEM operations (wave-uniform)
     // stage (h, kind): kind 0 / 1 = rows [64 h + 32 kind, + 32) of Wq (swizzled, 5 pieces per thread); kind 2 / 3 = output channels
     // [160 (kind - 2), + 160) of head h's packed Wo slice (linear, 6 rounds)
-    auto issue_stage = [&](int h, int kind, int slot) {
+    auto issue_stage = [&](int t, int slot) {    // stage t = (head t / 4, kind t % 4)
+        const int h = t >> 2, kind = t & 3;
         char* dst = ring + slot * SLOT + wave * 1024;
         if (kind < 2) {
 #pragma unroll
@@ -110,8 +118,8 @@ __global__ __launch_bounds__(256, 1) void xattn_full_kernel(const Args a) {
         const size_t g = (size_t)n * HEADS + h;
         const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.Kp) + g * (NKP * KLD), 0, (unsigned)KTILE, 0x00020000);
         const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.Vt) + g * (D * VLD), 0, (unsigned)VTILE, 0x00020000);
-        char* kd = kbuf + (h & 1) * KVBUF + wave * 1024;
-        char* vd = vbuf + (h & 1) * KVBUF + wave * 1024;
+        char* kd = kbuf + wave * 1024;
+        char* vd = vbuf + wave * 1024;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(kd + r * 4096), 16, (unsigned)((r * 256 + tid) * 16), 0, 0, 0);
@@ -127,9 +135,12 @@ __global__ __launch_bounds__(256, 1) void xattn_full_kernel(const Args a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const h16x8*>(xp + ks * 16);
     }
-    int m_w;                                     // value of vm_issued right after the awaited weight stage was issued
+    // marks: mk[i] = value of vm_issued right after stage (current + i) was issued; the ring keeps NST - 1 stages in flight
+    int mk[NST - 1];
     issue_kv(0);
-    issue_stage(0, 0, 0); m_w = vm_issued;
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) { issue_stage(i, i); mk[i] = vm_issued; }
+    int rd_slot = 0, wr_slot = NST - 1;          // slot of the stage being multiplied / of the next stage to issue
     // ---- LayerNorm of the panel (same arithmetic and rounding point as layernorm_kernel / linear_xs PRE = 1)
     {
         typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -201,15 +212,20 @@ __global__ __launch_bounds__(256, 1) void xattn_full_kernel(const Args a) {
         static_for<0, 4>([&](auto Kc) {
             constexpr int kind = decltype(Kc)::value;
             const int s = 4 * h + kind;
-            if (s == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): panel, stage 0, first K / V tile
-            else wait_vm_n(vm_issued - m_w);                    // stage s has landed
+            if (s == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): panel, LayerNorm vectors, first K / V^T tile, the prologue's stages
+            else wait_vm_n(vm_issued - mk[0]);                  // stage s has landed; the NST - 2 stages behind it may stay in flight
             asm volatile("s_barrier" ::: "memory");
-            // the slot stage s - 1 just left takes stage s + 1; the K / V buffers head h - 1 left take head h + 1 (issued BEHIND a weight
-            // stage, so the wait for the following stage covers them: VMEM retires in order)
-            if (kind < 3) { issue_stage(h, kind + 1, (s + 1) & 1); m_w = vm_issued; }
-            else if (h + 1 < HEADS) { issue_stage(h + 1, 0, (s + 1) & 1); m_w = vm_issued; }
-            if (kind == 0 && h + 1 < HEADS) issue_kv(h + 1);
-            const char* sW = ring + (s & 1) * SLOT;
+#pragma unroll
+            for (int i = 0; i + 1 < NST - 1; ++i) mk[i] = mk[i + 1];
+            // the K / V^T buffers are free once every wave is past the attention of head h (it sits in the kind-1 step, i.e. before this
+            // barrier when kind == 2); the next head's tiles are issued AHEAD of stage s + NST - 1 = (h + 1, kind 1), whose wait -- at the
+            // step that runs the attention of head h + 1 -- therefore covers them (VMEM retires in order), and that step's barrier
+            // publishes every wave's part
+            if (kind == 2 && h + 1 < HEADS) issue_kv(h + 1);
+            if (s + NST - 1 < NSTAGE) { issue_stage(s + NST - 1, wr_slot); mk[NST - 2] = vm_issued; }    // into the slot stage s - 1 just left
+            wr_slot = (wr_slot + 1 == NST) ? 0 : wr_slot + 1;
+            const char* sW = ring + rd_slot * SLOT;
+            rd_slot = (rd_slot + 1 == NST) ? 0 : rd_slot + 1;
             if constexpr (kind < 2) {
                 // ---- Q_h^T block `kind` = Wq rows x X^T
 #pragma unroll
@@ -233,9 +249,9 @@ __global__ __launch_bounds__(256, 1) void xattn_full_kernel(const Args a) {
                 }
             }
             if constexpr (kind == 1) {
-                // ================= attention of head h (its K / V^T tiles were complete at this head's first barrier) =================
-                const h16* kt = reinterpret_cast<const h16*>(kbuf + (h & 1) * KVBUF);
-                const h16* vt = reinterpret_cast<const h16*>(vbuf + (h & 1) * KVBUF);
+                // ================= attention of head h (its K / V^T tiles were complete at this step's barrier) =================
+                const h16* kt = reinterpret_cast<const h16*>(kbuf);
+                const h16* vt = reinterpret_cast<const h16*>(vbuf);
                 // ---- Q fragments: the accumulator blocks, rounded as the stand-alone path rounds them (fp16 Q, then fp16(Q * scale * log2 e))
                 h16x8 qf[4];
 #pragma unroll

@@ -11,6 +11,7 @@ STAGE = 32 * C * 2
 OSTAGE = 160 * OLD * 2
 SLOT = 6 * 4096
 KVBUF = 16384
+NST = 4            # ring depth (the K / V^T tiles are single-buffered)
 PLD = 40
 T = 256           # pixels per sample in this toy run (a workgroup's 128 pixels lie in one sample)
 WG = 1            # the workgroup emulated (pixels 128..255)
@@ -57,9 +58,9 @@ Wq_f, Kp_f, Vt_f, Wop_f = Wq.reshape(-1), Kp.reshape(-1), Vt.reshape(-1), Wop.re
 scale, eps = 0.125, 1e-5
 
 # ---- LDS (halves)
-lds = np.zeros((2 * SLOT + 4 * KVBUF + 4 * 32 * PLD * 2) // 2)
-RING, KB, VB = 0, 2 * SLOT // 2, (2 * SLOT + 2 * KVBUF) // 2
-PATCH0 = (2 * SLOT + 4 * KVBUF) // 2
+lds = np.zeros((NST * SLOT + 2 * KVBUF + 4 * 32 * PLD * 2) // 2)
+RING, KB, VB = 0, NST * SLOT // 2, (NST * SLOT + KVBUF) // 2
+PATCH0 = (NST * SLOT + 2 * KVBUF) // 2
 n = (WG * 128) // T
 
 
@@ -71,7 +72,8 @@ def dma(dst_half, src, src_half_off, limit_bytes):
         lds[dst_half:dst_half + 8] = 0.0
 
 
-def issue_stage(h, kind, slot):
+def issue_stage(t, slot):
+    h, kind = t >> 2, t & 3
     for tid in range(256):
         wave, lane = tid >> 6, tid & 63
         dst_b = RING * 2 + slot * SLOT + wave * 1024 + lane * 16
@@ -94,8 +96,8 @@ def issue_kv(h):
         wave, lane = tid >> 6, tid & 63
         for r in range(4):
             off = ((r * 256 + tid) * 16) // 2
-            dma((KB * 2 + (h & 1) * KVBUF + wave * 1024 + lane * 16 + r * 4096) // 2, Kp_f[gidx * NKP * KLD:], off, NKP * KLD * 2)
-            dma((VB * 2 + (h & 1) * KVBUF + wave * 1024 + lane * 16 + r * 4096) // 2, Vt_f[gidx * D * VLD:], off, D * VLD * 2)
+            dma((KB * 2 + wave * 1024 + lane * 16 + r * 4096) // 2, Kp_f[gidx * NKP * KLD:], off, NKP * KLD * 2)
+            dma((VB * 2 + wave * 1024 + lane * 16 + r * 4096) // 2, Vt_f[gidx * D * VLD:], off, D * VLD * 2)
 
 
 def a_pieces(base_half, row_stride, row0, col):
@@ -122,20 +124,23 @@ for wave in range(4):
         xf.append(B)
     state.append(dict(p0=p0, xf=xf, yacc=[np.zeros((L, 16)) for _ in range(10)]))
 
-issue_kv(0); issue_stage(0, 0, 0)
+issue_kv(0)
+for i in range(NST - 1):
+    issue_stage(i, i)
+rd_slot, wr_slot = 0, NST - 1
 for h in range(HEADS):
     for st in state:
         st["qacc"] = [np.zeros((L, 16)) for _ in range(2)]
     for kind in range(4):
         s = 4 * h + kind
-        # (barrier) next stage into the other slot, next head's K / V tiles
-        if kind < 3:
-            issue_stage(h, kind + 1, (s + 1) & 1)
-        elif h + 1 < HEADS:
-            issue_stage(h + 1, 0, (s + 1) & 1)
-        if kind == 0 and h + 1 < HEADS:
+        # (barrier) DMAs land the moment they are issued here -- the earliest they can: an overwrite of something still needed shows up
+        if kind == 2 and h + 1 < HEADS:
             issue_kv(h + 1)
-        sW = (RING * 2 + (s & 1) * SLOT) // 2
+        if s + NST - 1 < 4 * HEADS:
+            issue_stage(s + NST - 1, wr_slot)
+        wr_slot = 0 if wr_slot + 1 == NST else wr_slot + 1
+        sW = (RING * 2 + rd_slot * SLOT) // 2
+        rd_slot = 0 if rd_slot + 1 == NST else rd_slot + 1
         for st in state:
             if kind < 2:
                 for k16 in range(KS):
@@ -153,7 +158,7 @@ for h in range(HEADS):
                         A = a_pieces(sW, OLD, 32 * jb, 32 * (ks2 >> 1) + 16 * (ks2 & 1))
                         st["yacc"][5 * (kind - 2) + jb] = mfma(A, st["of"][ks2], st["yacc"][5 * (kind - 2) + jb])
             if kind == 1:
-                kt = (KB * 2 + (h & 1) * KVBUF) // 2; vt = (VB * 2 + (h & 1) * KVBUF) // 2
+                kt = (KB * 2) // 2; vt = (VB * 2) // 2
                 qf = [b_from_acc(st["qacc"][b], gp, scale) for b in range(2) for gp in range(2)]
                 sc = [np.zeros((L, 16)) for _ in range(3)]
                 for kb in range(3):

@@ -38,7 +38,9 @@ constexpr int VTILE = D * VLD * 2;               // 12 800 B
 constexpr int KVBUF = 16384;                     // both tiles land in whole 4 KB DMA rounds
 constexpr int PLD = 72;                          // halves per patch row (64 d + 8 pad)
 constexpr int PATCH = 32 * PLD * 2;
-constexpr int SMEM = 2 * STAGE + 4 * KVBUF + 4 * PATCH;
+constexpr int NST = 3;                           // ring depth: ONE workgroup per CU, nobody else covers a stage's round trip
+constexpr int NSTAGE = 2 * HEADS;
+constexpr int SMEM = NST * STAGE + 4 * KVBUF + 4 * PATCH;
 
 struct Args {
     const h16* x; const h16* ln_g; const h16* ln_b; float ln_eps;
@@ -49,11 +51,15 @@ struct Args {
 };
 
 #define VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+// wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform; clamping down is conservative; the
+// counter has 6 bits)
 __device__ __forceinline__ void wait_vm_n(int n) {
-    switch (n < 24 ? n : 24) {
+    switch (n < 48 ? n : 48) {
         VM_CASE(1) VM_CASE(2) VM_CASE(3) VM_CASE(4) VM_CASE(5) VM_CASE(6) VM_CASE(7) VM_CASE(8) VM_CASE(9) VM_CASE(10) VM_CASE(11) VM_CASE(12)
         VM_CASE(13) VM_CASE(14) VM_CASE(15) VM_CASE(16) VM_CASE(17) VM_CASE(18) VM_CASE(19) VM_CASE(20) VM_CASE(21) VM_CASE(22) VM_CASE(23)
-        VM_CASE(24)
+        VM_CASE(24) VM_CASE(25) VM_CASE(26) VM_CASE(27) VM_CASE(28) VM_CASE(29) VM_CASE(30) VM_CASE(31) VM_CASE(32) VM_CASE(33) VM_CASE(34)
+        VM_CASE(35) VM_CASE(36) VM_CASE(37) VM_CASE(38) VM_CASE(39) VM_CASE(40) VM_CASE(41) VM_CASE(42) VM_CASE(43) VM_CASE(44) VM_CASE(45)
+        VM_CASE(46) VM_CASE(47) VM_CASE(48)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -67,7 +73,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 __global__ __launch_bounds__(256, 1) void xattn_q_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
-    char* kbuf = smem + 2 * STAGE;               // [2][KVBUF]
+    char* kbuf = smem + NST * STAGE;             // [2][KVBUF]
     char* vbuf = kbuf + 2 * KVBUF;               // [2][KVBUF]
     char* patch_base = vbuf + 2 * KVBUF;
 
@@ -88,8 +94,8 @@ __global__ __launch_bounds__(256, 1) void xattn_q_kernel(const Args a) {
         wrel[j] = (unsigned)((row * C + c * 8) * 2);
     }
     int vm_issued = 0;                           // running count of this wave's VMEM operations (wave-uniform)
-    auto issue_w = [&](int s) {                  // stage s = rows [32 s, 32 s + 32) of Wq = (head s / 2, d block s % 2)
-        char* dst = ring + (s & 1) * STAGE + wave * 1024;
+    auto issue_w = [&](int s, int slot) {        // stage s = rows [32 s, 32 s + 32) of Wq = (head s / 2, d block s % 2)
+        char* dst = ring + slot * STAGE + wave * 1024;
 #pragma unroll
         for (int j = 0; j < W_DMA; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + j * 4096), 16, wrel[j] + (unsigned)(s * STAGE), 0, 0, 0);
@@ -117,9 +123,12 @@ __global__ __launch_bounds__(256, 1) void xattn_q_kernel(const Args a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const h16x8*>(xp + ks * 16);
     }
-    int m_w;                                     // value of vm_issued right after the awaited weight stage was issued
+    // marks: mk[i] = value of vm_issued right after stage (current + i) was issued; the ring keeps NST - 1 stages in flight
+    int mk[NST - 1];
     issue_kv(0);
-    issue_w(0); m_w = vm_issued;
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) { issue_w(i, i); mk[i] = vm_issued; }
+    int rd_slot = 0, wr_slot = NST - 1;
     // ---- LayerNorm of the panel (same arithmetic and rounding point as layernorm_kernel / linear_xs PRE = 1)
     {
         typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -186,20 +195,26 @@ __global__ __launch_bounds__(256, 1) void xattn_q_kernel(const Args a) {
         static_for<0, 2>([&](auto Bc) {
             constexpr int b = decltype(Bc)::value;
             const int s = 2 * h + b;
-            if (s == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): panel, stage 0, first K / V tile
-            else wait_vm_n(vm_issued - m_w);                    // stage s has landed
+            if (s == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): panel, LayerNorm vectors, first K / V^T tile, the prologue's stages
+            else wait_vm_n(vm_issued - mk[0]);                  // stage s has landed; the NST - 2 stages behind it may stay in flight
             asm volatile("s_barrier" ::: "memory");
-            if (s + 1 < 2 * HEADS) { issue_w(s + 1); m_w = vm_issued; }            // the slot stage s - 1 just left
-            if (b == 0 && h + 1 < HEADS) issue_kv(h + 1);                          // the buffers head h - 1 just left
-            const char* sW = ring + (s & 1) * STAGE;
+#pragma unroll
+            for (int i = 0; i + 1 < NST - 1; ++i) mk[i] = mk[i + 1];
+            // the K / V^T buffers head h - 1 left (every wave is past its attention: it sits before this barrier) take head h + 1; issued
+            // AHEAD of stage s + NST - 1 = (h + 1, block 0), whose wait -- one step before that head's attention -- covers them
+            if (b == 0 && h + 1 < HEADS) issue_kv(h + 1);
+            if (s + NST - 1 < NSTAGE) { issue_w(s + NST - 1, wr_slot); mk[NST - 2] = vm_issued; }      // into the slot stage s - 1 just left
+            wr_slot = (wr_slot + 1 == NST) ? 0 : wr_slot + 1;
+            const char* sW = ring + rd_slot * STAGE;
+            rd_slot = (rd_slot + 1 == NST) ? 0 : rd_slot + 1;
 #pragma unroll
             for (int k16 = 0; k16 < KS; ++k16) {
                 const h16x8 af = *reinterpret_cast<const h16x8*>(sW + aoff[k16 & 3] + (((2 * k16) & ~7) << 4));
                 qacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[k16], qacc[b], 0, 0, 0);
             }
         });
-        // ---- the K / V^T tiles of this head were issued one head ahead, BEFORE weight stage 2h (head 0: in the prologue): the wait for
-        //      stage 2h covered them (VMEM retires in order) and that stage's barrier published every wave's part
+        // ---- the K / V^T tiles of this head were issued one head ahead, in front of weight stage 2h (head 0: in the prologue): the wait
+        //      for stage 2h covered them (VMEM retires in order) and that step's barrier published every wave's part
         const h16* kt = reinterpret_cast<const h16*>(kbuf + (h & 1) * KVBUF);
         const h16* vt = reinterpret_cast<const h16*>(vbuf + (h & 1) * KVBUF);
         // ---- Q fragments: the accumulator blocks, rounded as the stand-alone path rounds them (fp16 Q, then fp16(Q * scale * log2 e))
