@@ -810,3 +810,15 @@ def test_bench_hbm_kernels_reads_the_committed_profiles(monkeypatch):
     t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24>")
     assert t is None and "stale" in why
     assert "note" in bench.hbm_kernels()["unet_forward"]
+
+
+def test_fragment_chain_emulations_of_the_fused_prototypes():
+    """tools/experiments/next: the stand-alone fused-block prototypes (xattn_q / xattn_full / ff_fused) rest on one identity -- a 32x32 MFMA
+    accumulator block is the B operand of the next product once the A side reads its rows as two 8-byte pieces -- and on a page of index
+    arithmetic (LDS-DMA swizzle, packed K / V^T / Wo / W2 tiles, ring slots, transpose patches).  The lane-level replays must keep agreeing
+    with the dense computation (they assert it themselves)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("mfma_chain_emu.py", "xattn_full_emu.py", "ff_fused_emu.py"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "next", name)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stdout[-400:], r.stderr[-400:])
+        assert "e-1" in r.stdout, (name, r.stdout)      # 1e-15-class agreement printed by each script
