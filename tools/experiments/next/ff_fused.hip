@@ -244,10 +244,14 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const Args a) {
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int r = 4 * (2 * gp + (i >> 2)) + (i & 3);                     // accumulator register
-                        const int row = 8 * (2 * gp + (i >> 2)) + 4 * hh + (i & 3);          // its row inside the 32-channel block
-                        hf[gp][i] = (h16)((ug[0][r] + (float)bu[row]) * gelu_f(ug[1][r] + (float)bg[row]));
+                    for (int q = 0; q < 2; ++q) {
+                        const int r0 = 4 * (2 * gp + q);                  // first accumulator register of this group of four
+                        const int row0 = 8 * (2 * gp + q) + 4 * hh;       // its row inside the 32-channel block
+                        const h16x4 bu4 = *reinterpret_cast<const h16x4*>(bu + row0);
+                        const h16x4 bg4 = *reinterpret_cast<const h16x4*>(bg + row0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            hf[gp][4 * q + e] = (h16)((ug[0][r0 + e] + (float)bu4[e]) * gelu_f(ug[1][r0 + e] + (float)bg4[e]));
                     }
             }
         });
