@@ -81,6 +81,10 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 
+// PIPE = 1: the GEGLU arithmetic of hidden block hb - 1 (320 VALU instructions per wave) is placed next to the u / g MFMAs of block hb (a
+// second pair of accumulator blocks), and the down-projection of a block runs one block late: at one wave per SIMD no other wave hides the
+// VALU work, the wave has to overlap it with its own MFMAs.  Ring order: u0 g0 | u1 g1 W2(0) | u2 g2 W2(1) | ... | W2(NB-1).
+template <int PIPE>
 __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
@@ -105,8 +109,16 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const Args a) {
     int vm_issued = 0;                           // running count of this wave's VMEM operations (wave-uniform)
     // stage (hb, kind): kind 0 / 1 = the u / g rows of hidden block hb (32-row block 2 hb + kind of the packed W1; swizzled, 5 pieces per
     // thread); kind 2 = the packed W2 slice of hidden block hb (linear, 6 rounds)
-    auto issue_stage = [&](int t, int slot) {    // stage t = (hidden block t / 3, kind t % 3)
-        const int hb = t / 3, kind = t - 3 * hb;
+    auto issue_stage = [&](int t, int slot) {    // PIPE 0: stage t = (hidden block t / 3, kind t % 3); PIPE 1: the order above
+        int hb, kind;
+        if (!PIPE) { hb = t / 3; kind = t - 3 * hb; }
+        else if (t < 2) { hb = 0; kind = t; }
+        else {
+            const int grp = (t - 2) / 3, k = (t - 2) - 3 * grp;
+            if (grp == NB - 1) { hb = NB - 1; kind = 2; }
+            else if (k < 2) { hb = grp + 1; kind = k; }
+            else { hb = grp; kind = 2; }
+        }
         char* dst = ring + slot * SLOT + wave * 1024;
         if (kind < 2) {
 #pragma unroll
@@ -197,64 +209,134 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.f;
 
-    for (int hb = 0; hb < NB; ++hb) {
-        f32x16 ug[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ug[b][r] = 0.f;
-        h16x8 hf[2];                             // the hidden block as B fragments (filled after the g stage)
-        static_for<0, 3>([&](auto Kc) {
-            constexpr int kind = decltype(Kc)::value;
-            const int s = 3 * hb + kind;
-            if (s == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): panel, LayerNorm vectors, bias, the prologue's stages
-            else wait_vm_n(vm_issued - mk[0]);                  // stage s has landed; the NST - 2 stages behind it may stay in flight
+    if constexpr (!PIPE) {
+        for (int hb = 0; hb < NB; ++hb) {
+            f32x16 ug[2];
+    #pragma unroll
+            for (int b = 0; b < 2; ++b)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) ug[b][r] = 0.f;
+            h16x8 hf[2];                             // the hidden block as B fragments (filled after the g stage)
+            static_for<0, 3>([&](auto Kc) {
+                constexpr int kind = decltype(Kc)::value;
+                const int s = 3 * hb + kind;
+                if (s == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): panel, LayerNorm vectors, bias, the prologue's stages
+                else wait_vm_n(vm_issued - mk[0]);                  // stage s has landed; the NST - 2 stages behind it may stay in flight
+                asm volatile("s_barrier" ::: "memory");
+    #pragma unroll
+                for (int i = 0; i + 1 < NST - 1; ++i) mk[i] = mk[i + 1];
+                if (s + NST - 1 < NSTAGE) { issue_stage(s + NST - 1, wr_slot); mk[NST - 2] = vm_issued; }    // into the slot stage s - 1 just left
+                wr_slot = (wr_slot + 1 == NST) ? 0 : wr_slot + 1;
+                const char* sW = ring + rd_slot * SLOT;
+                rd_slot = (rd_slot + 1 == NST) ? 0 : rd_slot + 1;
+                if constexpr (kind < 2) {
+    #pragma unroll
+                    for (int k16 = 0; k16 < KS; ++k16) {
+                        const h16x8 af = *reinterpret_cast<const h16x8*>(sW + aoff[k16 & 3] + (((2 * k16) & ~7) << 4));
+                        ug[kind] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[k16], ug[kind], 0, 0, 0);
+                    }
+                } else {
+                    // ---- out^T += W2 slice x h (k = hidden channel inside the block, in accumulator-row order)
+                    const h16* wd = reinterpret_cast<const h16*>(sW);
+    #pragma unroll
+                    for (int ob = 0; ob < 10; ++ob) {
+    #pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            const h16* rowp = wd + (32 * ob + l31) * DLD + 16 * gp + 4 * hh;
+                            const h16x4 lo = *reinterpret_cast<const h16x4*>(rowp);
+                            const h16x4 hi = *reinterpret_cast<const h16x4*>(rowp + 8);
+                            const h16x8 af = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            yacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, hf[gp], yacc[ob], 0, 0, 0);
+                        }
+                    }
+                }
+                if constexpr (kind == 1) {
+                    // ---- h = fp16((u + bu) * gelu(g + bg)): the GEGLU epilogue of linear_xs MODE 2, kept in registers as B fragments
+                    const h16* bu = bias_s + (2 * hb) * 32;
+                    const h16* bg = bu + 32;
+    #pragma unroll
+                    for (int gp = 0; gp < 2; ++gp)
+    #pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int r0 = 4 * (2 * gp + q);                  // first accumulator register of this group of four
+                            const int row0 = 8 * (2 * gp + q) + 4 * hh;       // its row inside the 32-channel block
+                            const h16x4 bu4 = *reinterpret_cast<const h16x4*>(bu + row0);
+                            const h16x4 bg4 = *reinterpret_cast<const h16x4*>(bg + row0);
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                hf[gp][4 * q + e] = (h16)((ug[0][r0 + e] + (float)bu4[e]) * gelu_f(ug[1][r0 + e] + (float)bg4[e]));
+                        }
+                }
+            });
+        }
+    } else {
+        static_assert(NB % 2 == 0, "the block loop is unrolled by two (two pairs of accumulator blocks with compile-time names)");
+        int step = 0;
+        auto begin = [&]() -> const char* {       // hand-over of the next ring stage (same protocol as the plain loop)
+            if (step == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else wait_vm_n(vm_issued - mk[0]);
             asm volatile("s_barrier" ::: "memory");
 #pragma unroll
             for (int i = 0; i + 1 < NST - 1; ++i) mk[i] = mk[i + 1];
-            if (s + NST - 1 < NSTAGE) { issue_stage(s + NST - 1, wr_slot); mk[NST - 2] = vm_issued; }    // into the slot stage s - 1 just left
+            if (step + NST - 1 < NSTAGE) { issue_stage(step + NST - 1, wr_slot); mk[NST - 2] = vm_issued; }
             wr_slot = (wr_slot + 1 == NST) ? 0 : wr_slot + 1;
             const char* sW = ring + rd_slot * SLOT;
             rd_slot = (rd_slot + 1 == NST) ? 0 : rd_slot + 1;
-            if constexpr (kind < 2) {
+            ++step;
+            return sW;
+        };
+        auto up = [&](const char* sW, f32x16& acc) {
 #pragma unroll
-                for (int k16 = 0; k16 < KS; ++k16) {
-                    const h16x8 af = *reinterpret_cast<const h16x8*>(sW + aoff[k16 & 3] + (((2 * k16) & ~7) << 4));
-                    ug[kind] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[k16], ug[kind], 0, 0, 0);
-                }
-            } else {
-                // ---- out^T += W2 slice x h (k = hidden channel inside the block, in accumulator-row order)
-                const h16* wd = reinterpret_cast<const h16*>(sW);
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int ob = 0; ob < 10; ++ob) {
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        const h16* rowp = wd + (32 * ob + l31) * DLD + 16 * gp + 4 * hh;
-                        const h16x4 lo = *reinterpret_cast<const h16x4*>(rowp);
-                        const h16x4 hi = *reinterpret_cast<const h16x4*>(rowp + 8);
-                        const h16x8 af = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        yacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, hf[gp], yacc[ob], 0, 0, 0);
-                    }
-                }
+            for (int k16 = 0; k16 < KS; ++k16) {
+                const h16x8 af = *reinterpret_cast<const h16x8*>(sW + aoff[k16 & 3] + (((2 * k16) & ~7) << 4));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[k16], acc, 0, 0, 0);
             }
-            if constexpr (kind == 1) {
-                // ---- h = fp16((u + bu) * gelu(g + bg)): the GEGLU epilogue of linear_xs MODE 2, kept in registers as B fragments
-                const h16* bu = bias_s + (2 * hb) * 32;
-                const h16* bg = bu + 32;
+        };
+        auto geglu_half = [&](const f32x16& u, const f32x16& g, int hb, int gp, h16x8& dst) {
+            const h16* bu = bias_s + (2 * hb) * 32;
+            const h16* bg = bu + 32;
 #pragma unroll
-                for (int gp = 0; gp < 2; ++gp)
+            for (int q = 0; q < 2; ++q) {
+                const int r0 = 4 * (2 * gp + q), row0 = 8 * (2 * gp + q) + 4 * hh;
+                const h16x4 bu4 = *reinterpret_cast<const h16x4*>(bu + row0);
+                const h16x4 bg4 = *reinterpret_cast<const h16x4*>(bg + row0);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int r0 = 4 * (2 * gp + q);                  // first accumulator register of this group of four
-                        const int row0 = 8 * (2 * gp + q) + 4 * hh;       // its row inside the 32-channel block
-                        const h16x4 bu4 = *reinterpret_cast<const h16x4*>(bu + row0);
-                        const h16x4 bg4 = *reinterpret_cast<const h16x4*>(bg + row0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            hf[gp][4 * q + e] = (h16)((ug[0][r0 + e] + (float)bu4[e]) * gelu_f(ug[1][r0 + e] + (float)bg4[e]));
-                    }
+                for (int e = 0; e < 4; ++e) dst[4 * q + e] = (h16)((u[r0 + e] + (float)bu4[e]) * gelu_f(g[r0 + e] + (float)bg4[e]));
             }
-        });
+        };
+        auto down = [&](const char* sW, const h16x8 (&hf)[2]) {
+            const h16* wd = reinterpret_cast<const h16*>(sW);
+#pragma unroll
+            for (int ob = 0; ob < 10; ++ob)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const h16* rowp = wd + (32 * ob + l31) * DLD + 16 * gp + 4 * hh;
+                    const h16x4 lo = *reinterpret_cast<const h16x4*>(rowp);
+                    const h16x4 hi = *reinterpret_cast<const h16x4*>(rowp + 8);
+                    const h16x8 af = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    yacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, hf[gp], yacc[ob], 0, 0, 0);
+                }
+        };
+        f32x16 uA, gA, uB, gB;
+        h16x8 hf[2];
+        up(begin(), uA);
+        up(begin(), gA);
+        for (int hb = 1; hb < NB; hb += 2) {
+            // block hb into (uB, gB) next to the GEGLU of block hb - 1 from (uA, gA)
+            { const char* sW = begin(); up(sW, uB); geglu_half(uA, gA, hb - 1, 0, hf[0]); }
+            { const char* sW = begin(); up(sW, gB); geglu_half(uA, gA, hb - 1, 1, hf[1]); }
+            down(begin(), hf);
+            if (hb + 1 < NB) {
+                { const char* sW = begin(); up(sW, uA); geglu_half(uB, gB, hb, 0, hf[0]); }
+                { const char* sW = begin(); up(sW, gA); geglu_half(uB, gB, hb, 1, hf[1]); }
+                down(begin(), hf);
+            }
+        }
+        geglu_half(uB, gB, NB - 1, 0, hf[0]);
+        geglu_half(uB, gB, NB - 1, 1, hf[1]);
+        down(begin(), hf);
     }
 
     // ---- epilogue (linear_xs MODE 1 rounding): fp16(acc + bias) + residual -> fp16, transposed through the wave's patch, 64-byte row segments
@@ -325,8 +407,12 @@ int main() {
     HIP_CHECK(hipMemcpy(dbo, bo.data(), C * 2, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemset(dout, 0, x.size() * 2));
     Args a{dx, dg, db, eps, dW1, db1, dW2, dbo, dx, dout, P};
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    hipLaunchKernelGGL(ff_fused_kernel, dim3(P / 128), dim3(256), SMEM, 0, a);
+  for (int variant = 0; variant < 2; ++variant) {
+    auto kfn = variant ? ff_fused_kernel<1> : ff_fused_kernel<0>;
+    printf("---- %s\n", variant ? "PIPE = 1 (GEGLU of block hb - 1 next to the MFMAs of block hb)" : "PIPE = 0 (plain)");
+    HIP_CHECK(hipMemset(dout, 0, x.size() * 2));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    hipLaunchKernelGGL(kfn, dim3(P / 128), dim3(256), SMEM, 0, a);
     HIP_CHECK(hipDeviceSynchronize());
     std::vector<h16> out(x.size());
     HIP_CHECK(hipMemcpy(out.data(), dout, out.size() * 2, hipMemcpyDeviceToHost));
@@ -361,10 +447,10 @@ int main() {
     printf("rel-L2 %.3e  max |err| %.3e  (fp16 storage: expect ~5e-4 / ~4e-3)\n", std::sqrt(sum_sq / ref_sq), max_err);
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(ff_fused_kernel, dim3(P / 128), dim3(256), SMEM, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(P / 128), dim3(256), SMEM, 0, a);
     HIP_CHECK(hipEventRecord(e0, 0));
     const int iters = 20;
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(ff_fused_kernel, dim3(P / 128), dim3(256), SMEM, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kfn, dim3(P / 128), dim3(256), SMEM, 0, a);
     HIP_CHECK(hipEventRecord(e1, 0));
     HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -376,5 +462,6 @@ int main() {
     size_t diff = 0;
     for (size_t i = 0; i < out.size(); ++i) diff += (float)out[i] != (float)out2[i];
     printf("repeat launches bit-equal: %s\n", diff == 0 ? "yes" : "NO");
+  }
     return 0;
 }
