@@ -84,7 +84,7 @@ def parse():
     p.add_argument("--no-tail", action="store_true", help="skip the D2H + PIL leg (with_d2h_pil_images_per_s)")
     p.add_argument("--lanes", type=int, default=None,
                    help="sample-group lanes of the UNet forward inside the denoising loop (csrc/runtime.h UNetLanes); default: the library's "
-                        "own choice (LADI_UNET_LANES, else 2)")
+                        "own choice (LADI_UNET_LANES, else 1: two concurrent half-batch forwards measured 3.5 % slower, DESIGN.md)")
     return p.parse_args()
 
 

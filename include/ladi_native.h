@@ -247,7 +247,7 @@ int ladi_tryon_set_trace(ladi_tryon* t, float* eps_trace_dev, float* latents_tra
 /* stage times (ms) of the last run: [0] preprocess + VAE encodes + EMASC, [1] denoising loop, [2] decode. Sync first. */
 int ladi_tryon_stage_ms(ladi_tryon* t, float* out3);
 /* sample-group lanes of the denoising loop: the UNet forward of the 2B (CFG) or B samples runs as `lanes` independent forwards on as
- * many HIP streams inside one hipGraph (csrc/runtime.h UNetLanes).  0 = default (environment LADI_UNET_LANES, else 2); a count that
+ * many HIP streams inside one hipGraph (csrc/runtime.h UNetLanes).  0 = default (environment LADI_UNET_LANES, else 1); a count that
  * does not divide the sample count falls back to the default rule.  Results do not depend on it beyond fp16 rounding of other tile
  * selections.  ladi_tryon_lanes() returns the count the last run used. */
 int ladi_tryon_set_lanes(ladi_tryon* t, int lanes);
@@ -256,7 +256,7 @@ int ladi_tryon_lanes(ladi_tryon* t);
  * and return the average milliseconds per forward (synchronises). Used by bench.py for the roofline figure. */
 int ladi_unet_time_forward(ladi_unet* u, int n, int h, int w, int iters, float* avg_ms, void* stream);
 /* the same measurement of the forward as the denoising loop runs it: `lanes` independent sample groups on as many HIP streams (0 =
- * the loop's own choice, LADI_UNET_LANES or 2; must divide n), replayed from one hipGraph with `lanes` parallel branches when
+ * the loop's own choice, LADI_UNET_LANES or 1; must divide n), replayed from one hipGraph with `lanes` parallel branches when
  * use_graph != 0.  Runs on an internal stream fenced against `stream`; synchronises. */
 int ladi_unet_time_forward_lanes(ladi_unet* u, int n, int h, int w, int iters, int lanes, int use_graph, float* avg_ms, void* stream);
 
@@ -300,6 +300,15 @@ int ladi_op_igemm(const ladi_igemm_desc* d, int batch, int tile_cfg, void* strea
 int ladi_op_group_norm(const void* src0, int C0, const void* src1, int C1, int n, int HW, int groups, const void* gamma,
                        const void* beta, float eps, int silu, const void* add, void* out, float* stats_scratch, void* stream);
 int ladi_op_layer_norm(const void* x, const void* gamma, const void* beta, float eps, int rows, int C, void* out, void* stream);
+/* Fused sub-blocks of diffusers' BasicTransformerBlock on the 320-channel level (5 heads of 64), fp16 operands in torch layout:
+ *   xattn: out = x + to_out(softmax(to_q(LayerNorm(x)) K^T / 8) V) with kv = [n][L][640] rows (K | V of the context, L <= 96), x / out [n*T][320],
+ *          T % 128 == 0 (norm2 / attn2 of the block: tryon_pipe.py:732 -> UNet2DConditionModel -> Transformer2DModel);
+ *   ff:    out = x + W2 ((u + bu) * gelu(g + bg)) + bo with (u | g) = W1 LayerNorm(x), W1 / b1 in the GEGLU packing of ladi_op_igemm (32-row blocks
+ *          alternate value | gate rows), w2 = [320][1280], P % 128 == 0 (norm3 / ff).  One launch each (ladi_vton_amd/csrc/xf_fused.hip). */
+int ladi_op_xattn_block(const void* x, const void* ln_gamma, const void* ln_beta, float eps, const void* wq, const void* kv, int L, const void* wo,
+                        const void* bo, int n, int T, void* out, void* stream);
+int ladi_op_ff_block(const void* x, const void* ln_gamma, const void* ln_beta, float eps, const void* w1_geglu, const void* b1_geglu, const void* w2,
+                     const void* bo, int P, void* out, void* stream);
 int ladi_op_attention(const void* q, const void* k, const void* v, void* o, int ldq, int ldk, int ldv, int ldo, long long sq,
                       long long sk, long long sv, long long so, int n, int heads, int Nq, int Nk, float scale, void* stream);
 /* same with causal = 1: query i attends to keys <= i (the CLIP text encoder's mask; Nq == Nk) */

@@ -144,6 +144,8 @@ SIGNATURES = {
     "ladi_op_igemm": (c_int, [POINTER(IGemmDesc), c_int, c_int, _P]),
     "ladi_op_group_norm": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, c_int, _P, _P, _P, _P]),
     "ladi_op_layer_norm": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),
+    "ladi_op_xattn_block": (c_int, [_P, _P, _P, c_float, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P]),
+    "ladi_op_ff_block": (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_int, _P, _P]),
     "ladi_op_attention": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,
                                   c_int, c_int, c_int, c_int, c_float, _P]),
     "ladi_op_attention_causal": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong,

@@ -470,7 +470,7 @@ __global__ void text_embed_kernel(const int* __restrict__ ids, const int* __rest
 // One wave per sentence; ids are clamped to the vocabulary by the caller's embedding lookup (no host round trip, hence no host error)
 __global__ void text_meta_kernel(const int* __restrict__ ids, int T, int vstar, int use_words, int* __restrict__ first, int* __restrict__ eot) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    int f = 0x7fffffff, best = -1, arg = 0x7fffffff;
+    int f = 0x7fffffff, best = (int)0x80000000, arg = 0x7fffffff;   // best = INT_MIN: a sentence of negative ids still finds its maximum
     for (int t = lane; t < T; t += 64) {
         const int id = ids[(size_t)b * T + t];
         if (id == vstar && t < f) f = t;
@@ -482,7 +482,7 @@ __global__ void text_meta_kernel(const int* __restrict__ ids, int T, int vstar, 
         f = min(f, f2);
         if (b2 > best || (b2 == best && a2 < arg)) { best = b2; arg = a2; }
     }
-    if (lane == 0) { first[b] = (use_words && f != 0x7fffffff) ? f : -1; eot[b] = b * T + arg; }
+    if (lane == 0) { first[b] = (use_words && f != 0x7fffffff) ? f : -1; eot[b] = b * T + min(max(arg, 0), T - 1); }   // row index always inside the sentence
 }
 // dst[i][:] = src[rows[i]][:]  (pooled output: the eot row of every sentence)
 __global__ void gather_rows_kernel(const h16* __restrict__ src, const int* __restrict__ rows, int H, h16* __restrict__ dst) {
@@ -706,7 +706,7 @@ __device__ __forceinline__ void st_any(void* p, int f32, size_t i, float v) {
 //   clipped to the image, weight = max(0, 1 - |(tap + 0.5 - centre) / max(scale, 1)|), normalised to sum 1.
 // One thread per output element evaluates the 2-D product of the two 1-D filters in fp32 (<= 7 x 7 taps for the 2.3x reductions here).
 // Optional value epilogue `e` (the CLIP image pre-processing of src/inference.py:268-272 in the same pass): v = v * pre_mul + pre_add,
-// clamp to [0, 1], then (v - sub[c]) / div[c] with c = plane % C.
+// clamp to [0, 1], floor to 1 / quant steps (quant > 0), then (v - sub[c]) / div[c] with c = plane % C.
 __global__ __launch_bounds__(256) void resize_bilinear_aa_kernel(const void* __restrict__ src, int in_f32, int planes, int H, int W,
                                                                  void* __restrict__ dst, int out_f32, int Ho, int Wo, const ResizeEpi e) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -735,6 +735,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_aa_kernel(const void* __r
     float v = acc / (wys * wxs);
     if (e.on) {
         v = fminf(fmaxf(v * e.pre_mul + e.pre_add, 0.f), 1.f);
+        // CLIPImageProcessor (transformers 4.27.3, the version the reference pins) sends a float image through to_pil_image on its way to
+        // `resize`: (x * 255).astype(uint8) -- a truncation -- and rescales by 1 / 255 afterwards, so the pixel values the vision encoder sees
+        // are floor-quantised to 8 bits
+        if (e.quant > 0.f) v = floorf(v * e.quant) / e.quant;
         const int c = (int)(pl % (size_t)e.C);
         v = (v - e.sub[c]) / e.div[c];
     }
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(256) void grid_sample_border_kernel(const void* __r
 int ladi_launch_resize_bilinear_aa(const void* src, int in_f32, int planes, int H, int W, void* dst, int out_f32, int Ho, int Wo,
                                    hipStream_t st, const ResizeEpi* epi) {
     if (planes <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return -1;
-    ResizeEpi e; e.on = 0; e.C = 1; e.pre_mul = 1.f; e.pre_add = 0.f;
+    ResizeEpi e; e.on = 0; e.C = 1; e.pre_mul = 1.f; e.pre_add = 0.f; e.quant = 0.f;
     for (int i = 0; i < 4; ++i) { e.sub[i] = 0.f; e.div[i] = 1.f; }
     if (epi) { e = *epi; if (e.C < 1 || e.C > 4) return -1; }
     const size_t total = (size_t)planes * Ho * Wo;

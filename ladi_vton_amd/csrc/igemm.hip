@@ -27,6 +27,7 @@
 #include <vector>
 #include <unordered_map>
 #include <map>
+#include <mutex>
 #include <array>
 #include <string>
 #include <cstdio>
@@ -231,17 +232,25 @@ inline bool is_lc(int base) { return base >= 62 && base <= 68; }
 // kernels whose every wave reaches the shared epilogue can combine their K slices in the launch (igemm_common.h igemm_splitk_combine); the
 // loader / consumer kernel (its loader waves hold no accumulators) and the X-stationary kernel keep the two-pass form
 inline bool sk_inline_ok(int base) { return base != 23 && base != 93 && !is_lc(base); }
-// arrival counters for launches that bring none (op-level entry points): zeroed once, every launch leaves them zeroed.  One stream at a
-// time -- the module graphs pass their own (launch_conv_into)
-int* g_sk_cnt = nullptr;
+// arrival counters for launches that bring none (op-level entry points and the module handles that set no Ctx::sk_cnt): one buffer per
+// (device, stream), zeroed once, every launch leaves it zeroed -- two handles working on different streams or devices at the same time
+// never share a tile's ticket.  Never freed (a captured graph may hold the pointer).
 constexpr int SK_MAX_TILES = 1024;
-bool ensure_sk_cnt(hipStream_t st) {
-    if (g_sk_cnt) return true;
+std::mutex g_sk_mu;
+std::map<std::pair<int, hipStream_t>, int*> g_sk_cnts;
+int* ensure_sk_cnt(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    auto it = g_sk_cnts.find({dev, st});
+    if (it != g_sk_cnts.end()) return it->second;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-    if (hipMalloc(reinterpret_cast<void**>(&g_sk_cnt), SK_MAX_TILES * sizeof(int)) != hipSuccess) { g_sk_cnt = nullptr; return false; }
-    if (hipMemset(g_sk_cnt, 0, SK_MAX_TILES * sizeof(int)) != hipSuccess) return false;
-    return true;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // no allocation inside a capture
+    int* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), SK_MAX_TILES * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, SK_MAX_TILES * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    g_sk_cnts[{dev, st}] = p;
+    return p;
 }
 int g_sk_two_pass = -1;       // -1: environment LADI_SPLITK_TWO_PASS decides (read once)
 bool sk_two_pass_forced() {
@@ -452,7 +461,9 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
     //      capture, every admissible configuration is timed with HIP events on the launch stream and the fastest is cached.
     //      Re-running a launch is idempotent (outputs never alias inputs in this library).
     // flags also carry the epilogue features that decide which kernels are admissible (residuals, fused statistics, other)
-    const int epi = ((a.bias_mul != 0.f && a.bias_mul != 1.f) ? 512 : 0) | (a.gn_ss ? 256 : 0) | (a.ln_gamma ? 128 : 0) | ((a.res0 || a.res1) ? 2 : 0) | (a.stats ? 8 : 0) |
+    // (bits 12 / 13 sit ABOVE the ksize field at bits 8..10: at 256 / 512 they were absorbed by ksize = 1 / 3 and a fused-GroupNorm
+    // projection shared its entry with the plain 1x1 of the same shape -- ADVICE r04)
+    const int epi = ((a.bias_mul != 0.f && a.bias_mul != 1.f) ? (1 << 13) : 0) | (a.gn_ss ? (1 << 12) : 0) | (a.ln_gamma ? 128 : 0) | ((a.res0 || a.res1) ? 2 : 0) | (a.stats ? 8 : 0) |
                     ((a.rowadd || a.mask || a.bias_per_pixel || a.out_f32 || a.out_scale != 1.f || (a.act != LADI_ACT_NONE && !geglu)) ? 64 : 0);
     TuneKey key{a.P, a.Q, a.K, a.C0, a.C1, a.Wo, (a.ksize << 8) | (a.stride << 4) | (a.ups << 2) | (geglu ? 1 : 0) | epi, batch};
     if (cfg == 0 && g_autotune) {
@@ -555,8 +566,8 @@ int ladi_launch_igemm(const IGemmArgs& a_in, int batch, int cfg, hipStream_t st,
         const long long tiles = (long long)((a.Q + kCfg[cfg].bq - 1) / kCfg[cfg].bq) * ((a.P + kCfg[cfg].bp - 1) / kCfg[cfg].bp);
         sk_inline = sk_inline_ok(kCfg[cfg].base) && !sk_two_pass_forced() && tiles <= SK_MAX_TILES;
         if (sk_inline && !sk_cnt) {
-            if (ensure_sk_cnt(st)) sk_cnt = g_sk_cnt;
-            else sk_inline = false;             // first use inside a capture without caller counters: two-pass form
+            sk_cnt = ensure_sk_cnt(st);
+            if (!sk_cnt) sk_inline = false;     // first use inside a capture without caller counters: two-pass form
         }
     }
     if (a.stats) {  // fused output statistics need whole 32*TP-pixel row blocks inside one sample

@@ -462,6 +462,7 @@ __device__ __forceinline__ bool igemm_splitk_combine(const IGemmArgs& a, f32x16 
         });
     });
     if (threadIdx.x == 0) __hip_atomic_store(a.sk_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();   // every wave has read its ticket from smem[0] before the epilogue reuses that word for its transpose patches
     return true;
 }
 

@@ -34,6 +34,35 @@ bool ladi_linear_xs_eligible(const IGemmArgs& a, int batch, int pb, int qs, int 
 int ladi_launch_linear_xs(const IGemmArgs& a, int pb, int qs, hipStream_t st, int nst = 3);
 void ladi_linear_xs_symbol(const IGemmArgs& a, int pb, int nst, char* out, int n);
 
+// ---- xf_fused.hip: fused transformer sub-blocks of the C = 320 level (5 heads of 64); see the file header for the operand packings
+struct XAttnBlockArgs {
+    const h16* x; const h16* ln_g; const h16* ln_b; float ln_eps;     // block input [P][320] (dense rows), LayerNorm (norm2)
+    const h16* Wq;                               // attn2.to_q [320][320] row-major, no bias
+    const h16* Kp; const h16* Vt;                // packed context tiles of the FIRST sample of x: [n][5][96][68], [n][5][64][100]
+    const h16* Wo; const h16* bo;                // attn2.to_out.0 packed [5][320][68], bias [320]
+    const h16* res;                              // residual [P][320] (normally == x)
+    h16* out;                                    // [P][320]
+    int P, T, nk; float scale;                   // pixels, pixels per sample (multiples of 128), context length (<= 96), 1 / sqrt(64)
+};
+struct FFBlockArgs {
+    const h16* x; const h16* ln_g; const h16* ln_b; float ln_eps;     // block input [P][320], LayerNorm (norm3)
+    const h16* W1; const h16* b1;                // ff.net.0.proj in the GEGLU packing [2560][320], [2560] (load_geglu)
+    const h16* W2; const h16* bo;                // ff.net.2 packed [40][320][36], bias [320]
+    const h16* res;                              // residual [P][320] (normally == x)
+    h16* out;
+    int P;
+};
+bool ladi_xf_fused_eligible(int C, int heads, int T, int L);
+size_t ladi_xf_kp_elems(int n);
+size_t ladi_xf_vt_elems(int n);
+size_t ladi_xf_wo_packed_elems();
+size_t ladi_xf_w2_packed_elems();
+int ladi_launch_pack_kv_tiles(const h16* kv, int n, int L, int C, h16* kp, h16* vt, hipStream_t st);   // kv [n][L][2C]
+int ladi_launch_pack_wo(const h16* Wo, h16* out, hipStream_t st);
+int ladi_launch_pack_w2(const h16* W2, h16* out, hipStream_t st);
+int ladi_launch_xattn_block(const XAttnBlockArgs& a, hipStream_t st);
+int ladi_launch_ff_block(const FFBlockArgs& a, hipStream_t st);        // LADI_FF_PIPE=0: the plain loop (A/B)
+
 // ---- norm.hip
 // GroupNorm in three stages (all atomics-free): per-channel partial statistics rows [rows][C][2] (written by the producing
 // igemm's epilogue, or by ladi_launch_gn_partial), finalize -> scale_shift[n][C0+C1][2], apply.
@@ -45,6 +74,12 @@ int ladi_launch_gn_finalize(const float* part0, int C0, int rps0, const float* p
 // y = act(x * scale + shift) (+ add) over the virtual concat (src0[C0] | src1[C1]): out [n][HW][C0+C1] dense
 int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int C1, int ld1, int n, int HW,
                          const float* scale_shift, int silu, const h16* add, h16* out, hipStream_t st);
+// one-pass form (round 5): every block finalises the groups of its own 64-channel chunk from the partial rows (few rows per sample only:
+// ladi_gn_norm_eligible) and applies -- no gn_finalize launch, no scale / shift table
+bool ladi_gn_norm_eligible(int C0, int rps0, int C1, int rps1, int groups);
+int ladi_launch_gn_norm(const h16* src0, int C0, int ld0, const float* part0, int rps0, const h16* src1, int C1, int ld1, const float* part1,
+                        int rps1, int n, int HW, int groups, const h16* gamma, const h16* beta, float eps, int silu, const h16* add, h16* out,
+                        hipStream_t st, int* bad = nullptr);
 int ladi_launch_layernorm(const h16* x, int ldx, const h16* gamma, const h16* beta, float eps, int rows, int C, h16* out,
                           int ldo, hipStream_t st);
 // P[r][:] = softmax(scale * S[r][:]) ; S fp32 [rows][cols], P fp16
@@ -147,7 +182,7 @@ int ladi_launch_maxpool2(const h16* src, int lds_, int n, int H, int W, int C, h
 int ladi_launch_upsample2x_bilinear_ac(const h16* src, int lds_, int n, int H, int W, int C, h16* dst, int ldd, hipStream_t st);
 // glue of the warping module (src/inference.py:242-260), NCHW planes, fp32 or fp16 in / out:
 // torchvision resize(BILINEAR, antialias=True) == aten _upsample_bilinear2d_aa (align_corners=False)
-struct ResizeEpi { int on, C; float pre_mul, pre_add; float sub[4], div[4]; };   // value epilogue, see elementwise.hip
+struct ResizeEpi { int on, C; float pre_mul, pre_add; float sub[4], div[4]; float quant; };   // value epilogue, see elementwise.hip (quant > 0: floor(v * quant) / quant after the clamp)
 int ladi_launch_resize_bilinear_aa(const void* src, int in_f32, int planes, int H, int W, void* dst, int out_f32, int Ho, int Wo,
                                    hipStream_t st, const ResizeEpi* epi = nullptr);
 // F.grid_sample(x, grid, bilinear, padding_mode="border", align_corners=False); grid fp32 [B][Ho][Wo][2] (x, y)

@@ -177,6 +177,111 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ s
     }
 }
 
+// GroupNorm in ONE pass over the data (round 5): finalize folded into apply.  Block = (pixel block, sample, 64-channel chunk): the block sums the
+// partial rows of the groups that overlap its chunk itself (at most 64 + 2 gs - 2 channels x rps rows of 8 bytes, L2-resident: the producer's
+// epilogue wrote them a moment ago), derives scale / shift for its 64 channels and streams its 128-byte row pieces.  Removes the gn_finalize
+// launch (6.8 us of launch latency and dependent loads for 1.8 MB of traffic, 61 per UNet forward) wherever the rows per sample are few; the
+// summation order is fixed (row lanes, then channels of a group), so the result is bitwise reproducible.  Same rounding point as
+// gn_finalize + gn_apply: statistics fp32, y = fp16(act(x * scale + shift) (+ add)).
+constexpr int GNX_CH = 64;          // channels per block
+constexpr int GNX_MAX_GS = 96;      // largest group size handled (channels per group); stat channels <= 64 + 2 * 96 - 2 <= 256
+constexpr int GNX_MAX_RPS = 32;     // more partial rows per sample than this: the three-stage form (VAE-sized tensors)
+__global__ __launch_bounds__(256) void gn_norm_kernel(const h16* __restrict__ src0, int C0, int ld0, const float* __restrict__ part0, int rps0,
+                                                      const h16* __restrict__ src1, int C1, int ld1, const float* __restrict__ part1, int rps1,
+                                                      int HW, int gs, const h16* __restrict__ gamma, const h16* __restrict__ beta, float eps,
+                                                      int silu, const h16* __restrict__ add, h16* __restrict__ out, int ppb, int* __restrict__ bad) {
+    __shared__ float rsum[256], rsq[256];
+    __shared__ float csum[256], csq[256];
+    __shared__ float gmean[GNX_CH + 2], grstd[GNX_CH + 2];
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int Ct = C0 + C1;
+    const int c0 = blockIdx.z * GNX_CH;
+    const int nch = min(GNX_CH, Ct - c0);
+    const int g_lo = c0 / gs, g_hi = (c0 + nch - 1) / gs, ng = g_hi - g_lo + 1;
+    const int cb = g_lo * gs, ncs = ng * gs;            // statistics channels [cb, cb + ncs): whole groups, <= 256
+    {
+        const int RL = 256 / ncs;                       // row lanes
+        const int cl = tid % ncs, rl = tid / ncs;
+        float s = 0.f, q = 0.f;
+        if (rl < RL) {
+            const int c = cb + cl;
+            const float* p; int C, rps, clc;
+            if (c < C0) { p = part0; C = C0; rps = rps0; clc = c; } else { p = part1; C = C1; rps = rps1; clc = c - C0; }
+            const float2* row = reinterpret_cast<const float2*>(p) + (size_t)n * rps * C + clc;
+            for (int r = rl; r < rps; r += RL) { const float2 v = row[(size_t)r * C]; s += v.x; q += v.y; }
+            rsum[rl * ncs + cl] = s; rsq[rl * ncs + cl] = q;
+        }
+        __syncthreads();
+        if (tid < ncs) {
+            float ts = 0.f, tq = 0.f;
+            for (int l = 0; l < RL; ++l) { ts += rsum[l * ncs + tid]; tq += rsq[l * ncs + tid]; }
+            csum[tid] = ts; csq[tid] = tq;
+        }
+        __syncthreads();
+        if (tid < ng) {
+            float ts = 0.f, tq = 0.f;
+            for (int c = tid * gs; c < (tid + 1) * gs; ++c) { ts += csum[c]; tq += csq[c]; }
+            const float inv = 1.f / ((float)gs * (float)HW);
+            const float mean = ts * inv;
+            const float var = fmaxf(tq * inv - mean * mean, 0.f);
+            gmean[tid] = mean; grstd[tid] = rsqrtf(var + eps);
+            if (bad && !(fabsf(ts) <= 3.0e38f && tq <= 3.0e38f)) *bad = 1;     // fp16-range guard (see gn_finalize_kernel)
+        }
+        __syncthreads();
+    }
+    const int my_o = tid & 7, my_p = tid >> 3;          // octet of the chunk, pixel lane (32 of them)
+    const int c = c0 + my_o * 8;
+    if (c >= Ct) return;
+    float sc[8], sh[8];
+    {
+        const h16x8 ga = *reinterpret_cast<const h16x8*>(gamma + c), be = *reinterpret_cast<const h16x8*>(beta + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / gs - g_lo;
+            sc[e] = (float)ga[e] * grstd[g];
+            sh[e] = (float)be[e] - gmean[g] * sc[e];
+        }
+    }
+    const h16* base; int ld;
+    if (c < C0) { base = src0 + c; ld = ld0; } else { base = src1 + (c - C0); ld = ld1; }
+    const int pix0 = blockIdx.x * ppb;
+    const int npix = min(ppb, HW - pix0);
+    const size_t row0 = (size_t)n * HW + pix0;
+    auto xform = [&](const h16x8& v, const h16x8& ad, const size_t row) {
+        h16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = (float)v[e] * sc[e] + sh[e];
+            if (silu) y = silu_fast(y);
+            if (add) y += (float)ad[e];
+            o[e] = (h16)y;
+        }
+        *reinterpret_cast<h16x8*>(out + row * Ct + c) = o;
+    };
+    const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    int p = my_p;
+    for (; p + 96 < npix; p += 128) {           // four independent 16-byte loads in flight (all loads of a round before its first store)
+        const h16x8 v0 = *reinterpret_cast<const h16x8*>(base + (row0 + p) * ld);
+        const h16x8 v1 = *reinterpret_cast<const h16x8*>(base + (row0 + p + 32) * ld);
+        const h16x8 v2 = *reinterpret_cast<const h16x8*>(base + (row0 + p + 64) * ld);
+        const h16x8 v3 = *reinterpret_cast<const h16x8*>(base + (row0 + p + 96) * ld);
+        h16x8 a0 = zero, a1 = zero, a2 = zero, a3 = zero;
+        if (add) {
+            a0 = *reinterpret_cast<const h16x8*>(add + (row0 + p) * Ct + c);
+            a1 = *reinterpret_cast<const h16x8*>(add + (row0 + p + 32) * Ct + c);
+            a2 = *reinterpret_cast<const h16x8*>(add + (row0 + p + 64) * Ct + c);
+            a3 = *reinterpret_cast<const h16x8*>(add + (row0 + p + 96) * Ct + c);
+        }
+        xform(v0, a0, row0 + p); xform(v1, a1, row0 + p + 32); xform(v2, a2, row0 + p + 64); xform(v3, a3, row0 + p + 96);
+    }
+    for (; p < npix; p += 32) {
+        const h16x8 v0 = *reinterpret_cast<const h16x8*>(base + (row0 + p) * ld);
+        h16x8 a0 = zero;
+        if (add) a0 = *reinterpret_cast<const h16x8*>(add + (row0 + p) * Ct + c);
+        xform(v0, a0, row0 + p);
+    }
+}
+
 // LayerNorm: each wave normalises R consecutive rows with all of their 16-byte loads in flight at once (rows are only 640 B - 2.5 KB,
 // so one row per wave leaves the memory system idle); statistics two-pass in registers. C % 8 == 0, C <= 64*8*MAXO.
 template <int R, int MAXO>
@@ -323,6 +428,33 @@ int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int 
     const int ppb = pick_ppb(n, HW, Ct >> 3);
     dim3 grid((HW + ppb - 1) / ppb, n);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, st, src0, C0, ld0, src1, C1, ld1, HW, scale_shift, silu, add, out, ppb);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+bool ladi_gn_norm_eligible(int C0, int rps0, int C1, int rps1, int groups) {
+    const char* e = getenv("LADI_GN_ONEPASS");       // read per call (host side, at graph-capture time): one process can A/B both forms
+    const bool on = !(e && e[0] == '0');
+    const int Ct = C0 + C1;
+    if (!on || groups <= 0 || (Ct % groups)) return false;
+    const int gs = Ct / groups;
+    return gs <= GNX_MAX_GS && rps0 >= 1 && rps0 <= GNX_MAX_RPS && (C1 == 0 || (rps1 >= 1 && rps1 <= GNX_MAX_RPS)) && groups * gs == Ct;
+}
+
+int ladi_launch_gn_norm(const h16* src0, int C0, int ld0, const float* part0, int rps0, const h16* src1, int C1, int ld1, const float* part1,
+                        int rps1, int n, int HW, int groups, const h16* gamma, const h16* beta, float eps, int silu, const h16* add, h16* out,
+                        hipStream_t st, int* bad) {
+    const int Ct = C0 + C1;
+    if ((C0 & 7) || (C1 & 7) || (ld0 & 7) || (C1 && (ld1 & 7)) || !ladi_gn_norm_eligible(C0, rps0, C1, rps1, groups)) return -1;
+    const int chunks = (Ct + GNX_CH - 1) / GNX_CH;
+    // pixels per block: 128-byte row pieces x ppb rows; halve until the grid has ~3 blocks per CU (LADI_GN_PPB pins it: sweeps)
+    const char* pe = getenv("LADI_GN_PPB");
+    const int pin = pe ? atoi(pe) : 0;
+    int ppb = 512;
+    if (pin >= 32) ppb = pin;
+    else while (ppb > 64 && (long long)n * chunks * ((HW + ppb - 1) / ppb) < 768) ppb >>= 1;
+    dim3 grid((HW + ppb - 1) / ppb, n, chunks);
+    hipLaunchKernelGGL(gn_norm_kernel, grid, dim3(256), 0, st, src0, C0, ld0, part0, rps0, src1, C1, ld1, part1, rps1, HW, Ct / groups, gamma, beta,
+                       eps, silu, add, out, ppb, bad);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 

@@ -122,6 +122,8 @@ struct ResBlock {
 struct XfBlock {
     DNorm gn, ln1, ln2, ln3; DConv proj_in, qkv, o1, q2, kv2, o2, ff1, ff2, proj_out; int C = 0, heads = 0;
     h16* kv_cache = nullptr;  // [n][L][2C]
+    // fused sub-blocks of the C = 320 level (xf_fused.hip): operands packed once at load (o2_packed, ff2_packed) / per context (kp, vt)
+    h16* o2_packed = nullptr; h16* ff2_packed = nullptr; h16* kp_tiles = nullptr; h16* vt_tiles = nullptr;
 };
 
 struct UNetCfg {
@@ -144,7 +146,7 @@ struct UNet {
     DConv down_samp[3], up_samp[3];
     int temb_total = 0;
     // context (cross-attention K/V) cache
-    int ctx_n = 0, ctx_L = 0, ctx_cap_n = 0;
+    int ctx_n = 0, ctx_L = 0, ctx_cap_n = 0, ctx_cap_samples = 0;    // cache capacity in rows (n * L) and, for the per-sample tiles, in samples
     std::unique_ptr<DevPool> ctx_pool;
     // time-embedding table
     float* temb_table = nullptr; int temb_rows_cap = 0; int temb_rows = 0;
@@ -177,7 +179,7 @@ struct UNetLanes {
     Arena arena[MAXG]; size_t peak[MAXG] = {};
     float* stats[MAXG] = {}; size_t stats_cap[MAXG] = {}, stats_peak[MAXG] = {};
     int* sk_cnt[MAXG] = {};                 // per-lane split-K arrival counters (lanes run concurrently)
-    static int pick(int n);                 // LADI_UNET_LANES (default 2), lowered until it divides n
+    static int pick(int n);                 // LADI_UNET_LANES (default 1), lowered until it divides n
     void configure(int n, int g = 0);       // g = 0: pick(n); creates the streams / events; a changed lane count drops the old plan
     void reset();                           // release every lane arena (streams / events / counters are kept)
     // x [n,h,w,64] -> eps [n,h,w,ld] (both caller-owned, contiguous in n).  dry: planning pass (records arena / statistics peaks, no

@@ -245,14 +245,12 @@ Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& 
 }
 
 // GroupNorm over the virtual concat (x | x2): partial statistics come from the producers' epilogues when available
-float* gn_scale_shift(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups, float eps) {
-    const int C0 = x.c, C1 = x2 ? x2->c : 0;
-    if (C0 + C1 != nm.c) throw std::runtime_error("group_norm: channel mismatch");
+namespace {
+struct GnParts { const float* part[2] = {nullptr, nullptr}; int rps[2] = {0, 0}; };
+GnParts gn_parts(Ctx& c, const Act& x, const Act* x2) {
     const int HW = x.h * x.w;
-    float* ss = c.alloc_f32((size_t)x.n * (C0 + C1) * 2);
     const Act* srcs[2] = {&x, x2};
-    const float* part[2] = {nullptr, nullptr};
-    int rps[2] = {0, 0};
+    GnParts g;
     for (int i = 0; i < 2; ++i) {
         const Act* s = srcs[i];
         if (!s) continue;
@@ -260,15 +258,25 @@ float* gn_scale_shift(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int 
         const int rows = ladi_gn_partial_rows(s->n, HW, s->c);
         float* p = c.alloc_f32((size_t)s->n * rows * s->c * 2);
         if (s->st_part && s->st_px > 0) {
-            part[i] = s->st_part;
-            rps[i] = HW / s->st_px;
+            g.part[i] = s->st_part;
+            g.rps[i] = HW / s->st_px;
         } else {
             if (!c.dry()) c.check(ladi_launch_gn_partial(s->p, s->c, s->ld, s->n, HW, p, c.st), "gn_partial");
-            part[i] = p; rps[i] = rows;
+            g.part[i] = p; g.rps[i] = rows;
         }
     }
+    return g;
+}
+}  // namespace
+
+float* gn_scale_shift(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups, float eps) {
+    const int C0 = x.c, C1 = x2 ? x2->c : 0;
+    if (C0 + C1 != nm.c) throw std::runtime_error("group_norm: channel mismatch");
+    const int HW = x.h * x.w;
+    float* ss = c.alloc_f32((size_t)x.n * (C0 + C1) * 2);
+    const GnParts g = gn_parts(c, x, x2);
     if (!c.dry())
-        c.check(ladi_launch_gn_finalize(part[0], C0, rps[0], part[1], C1, rps[1], x.n, HW, groups, nm.g, nm.b, eps, ss, c.st, c.bad), "gn_finalize");
+        c.check(ladi_launch_gn_finalize(g.part[0], C0, g.rps[0], g.part[1], C1, g.rps[1], x.n, HW, groups, nm.g, nm.b, eps, ss, c.st, c.bad), "gn_finalize");
     return ss;
 }
 
@@ -277,8 +285,17 @@ Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups,
     if (C0 + C1 != nm.c) throw std::runtime_error("group_norm: channel mismatch");
     const int HW = x.h * x.w;
     Act out = c.new_act(x.n, x.h, x.w, C0 + C1);
-    float* ss = gn_scale_shift(c, nm, x, x2, groups, eps);
+    // (the scale / shift table is reserved whichever form runs: the arena plan does not depend on LADI_GN_ONEPASS)
+    float* ss = c.alloc_f32((size_t)x.n * (C0 + C1) * 2);
+    const GnParts g = gn_parts(c, x, x2);
     if (c.dry()) return out;
+    if (ladi_gn_norm_eligible(C0, g.rps[0], C1, g.rps[1], groups)) {
+        // few partial rows per sample (every UNet level): each block finalises its own 64-channel chunk -- one launch instead of two
+        c.check(ladi_launch_gn_norm(x.p, C0, x.ld, g.part[0], g.rps[0], x2 ? x2->p : nullptr, C1, x2 ? x2->ld : 0, g.part[1], g.rps[1], x.n, HW, groups,
+                                    nm.g, nm.b, eps, silu, add ? add->p : nullptr, out.p, c.st, c.bad), "gn_norm");
+        return out;
+    }
+    c.check(ladi_launch_gn_finalize(g.part[0], C0, g.rps[0], g.part[1], C1, g.rps[1], x.n, HW, groups, nm.g, nm.b, eps, ss, c.st, c.bad), "gn_finalize");
     c.check(ladi_launch_gn_apply(x.p, C0, x.ld, x2 ? x2->p : nullptr, C1, x2 ? x2->ld : 0, x.n, HW, ss, silu, add ? add->p : nullptr, out.p,
                                  c.st), "gn_apply");
     return out;

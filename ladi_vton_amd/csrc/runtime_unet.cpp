@@ -43,6 +43,13 @@ static XfBlock load_xf(DevPool& pool, const WeightStore& ws, const std::string& 
     x.C = x.proj_in.cout;
     x.heads = heads;
     if (x.C != heads * 64) throw std::runtime_error(p + ": head_dim must be 64");
+    // the C = 320 level runs attn2 and the feed-forward as fused kernels (xf_fused.hip): pack to_out / ff.net.2 per head / per hidden block
+    if (ladi_xf_fused_eligible(x.C, heads, 128, 1) && x.o2.cin_pad == x.C && x.ff2.cin_pad == 4 * x.C && x.ff1.cout == 8 * x.C) {
+        x.o2_packed = reinterpret_cast<h16*>(pool.alloc(ladi_xf_wo_packed_elems() * sizeof(h16)));
+        x.ff2_packed = reinterpret_cast<h16*>(pool.alloc(ladi_xf_w2_packed_elems() * sizeof(h16)));
+        if (ladi_launch_pack_wo(x.o2.w, x.o2_packed, nullptr) || ladi_launch_pack_w2(x.ff2.w, x.ff2_packed, nullptr) || hipDeviceSynchronize() != hipSuccess)
+            throw std::runtime_error(p + ": packing the fused-block operands failed");
+    }
     return x;
 }
 
@@ -97,10 +104,16 @@ int UNet::set_context(const h16* ehs, int n, int L, hipStream_t st) {
     for (auto& x : down_xf) all.push_back(&x);
     all.push_back(&mid_xf);
     for (auto& x : up_xf) all.push_back(&x);
-    if (n * L > ctx_cap_n) {
+    if (n * L > ctx_cap_n || n > ctx_cap_samples) {
         ctx_pool.reset(new DevPool());   // frees the previous (smaller) K/V cache
-        for (auto* x : all) x->kv_cache = reinterpret_cast<h16*>(ctx_pool->alloc((size_t)n * L * 2 * x->C * sizeof(h16)));
-        ctx_cap_n = n * L;
+        for (auto* x : all) {
+            x->kv_cache = reinterpret_cast<h16*>(ctx_pool->alloc((size_t)n * L * 2 * x->C * sizeof(h16)));
+            if (x->o2_packed) {
+                x->kp_tiles = reinterpret_cast<h16*>(ctx_pool->alloc(ladi_xf_kp_elems(n) * sizeof(h16)));
+                x->vt_tiles = reinterpret_cast<h16*>(ctx_pool->alloc(ladi_xf_vt_elems(n) * sizeof(h16)));
+            }
+        }
+        ctx_cap_n = n * L; ctx_cap_samples = n;
     }
     ctx_n = n; ctx_L = L;
     for (auto* x : all) {
@@ -112,6 +125,10 @@ int UNet::set_context(const h16* ehs, int n, int L, hipStream_t st) {
         a.out = x->kv_cache; a.ldo = 2 * x->C; a.out_scale = 1.f;
         int rc = ladi_launch_igemm(a, 1, 0, st);
         if (rc) { set_error("set_context igemm rc=" + std::to_string(rc)); return rc; }
+        if (x->kp_tiles && ladi_xf_fused_eligible(x->C, x->heads, 128, L)) {      // the fused attn2 reads per-(sample, head) tiles
+            rc = ladi_launch_pack_kv_tiles(x->kv_cache, n, L, x->C, x->kp_tiles, x->vt_tiles, st);
+            if (rc) { set_error("set_context pack_kv_tiles rc=" + std::to_string(rc)); return rc; }
+        }
     }
     return 0;
 }
@@ -207,16 +224,51 @@ struct Fwd {
         Act o1 = attn(qkv.p, 3 * C, (long long)T * 3 * C, qkv.p + C, qkv.p + 2 * C, 3 * C, (long long)T * 3 * C, n, T, T, b.heads);
         ConvOpt or1; or1.res0 = &t0;
         Act t1 = conv2d(c, b.o1, o1, nullptr, or1);
-        ConvOpt oq2; oq2.ln = &b.ln2;
-        Act q2 = conv2d(c, b.q2, t1, nullptr, oq2);
-        const h16* kv = b.kv_cache + (size_t)sample0 * u.ctx_L * 2 * C;     // this lane's samples of the cached cross-attention K / V
-        Act o2 = attn(q2.p, C, (long long)T * C, kv, kv + C, 2 * C, (long long)u.ctx_L * 2 * C, n, T, u.ctx_L, b.heads);
-        ConvOpt or2; or2.res0 = &t1;
-        Act t2 = conv2d(c, b.o2, o2, nullptr, or2);
-        ConvOpt og; og.act = LADI_ACT_GEGLU; og.ln = &b.ln3;
-        Act gg = conv2d(c, b.ff1, t2, nullptr, og);
-        ConvOpt or3; or3.res0 = &t2;
-        Act t3 = conv2d(c, b.ff2, gg, nullptr, or3);
+        // attn2 and the feed-forward as ONE kernel each on the C = 320 level (xf_fused.hip; LADI_XF_FUSE=0 / =1 / =2: none / attn2 only / both,
+        // read per call so that a planning pass and its real pass agree and one process can A/B), else the chain of projections.  Measured on
+        // MI355X (profiles/r05_xf_fused_ab.txt): parity-green and bit-reproducible, but at one wave per SIMD the fused chains expose the latency two
+        // waves per SIMD hide in the separate launches -- attn2 85.7 us against the ~76 us of the three launches it replaces (forward
+        // +0.05 ms), feed-forward 275 us against 109 + 57 us (forward +0.45 ms) -- so the DEFAULT IS OFF; the kernels stay selectable.
+        int fuse = 0;
+        if (b.o2_packed && b.kp_tiles && t1.ld == C && ladi_xf_fused_eligible(C, b.heads, T, u.ctx_L)) {
+            const char* e = getenv("LADI_XF_FUSE");
+            fuse = e ? atoi(e) : 0;
+        }
+        Act t2;
+        if (fuse >= 1) {
+            t2 = c.new_act(n, T, 1, C);
+            if (!c.dry()) {
+                XAttnBlockArgs xa;
+                xa.x = t1.p; xa.ln_g = b.ln2.g; xa.ln_b = b.ln2.b; xa.ln_eps = 1e-5f;
+                xa.Wq = b.q2.w;
+                xa.Kp = b.kp_tiles + ladi_xf_kp_elems(sample0); xa.Vt = b.vt_tiles + ladi_xf_vt_elems(sample0);
+                xa.Wo = b.o2_packed; xa.bo = b.o2.b; xa.res = t1.p; xa.out = t2.p;
+                xa.P = n * T; xa.T = T; xa.nk = u.ctx_L; xa.scale = 0.125f;
+                c.check(ladi_launch_xattn_block(xa, c.st), "xattn_block");
+            }
+        } else {
+            ConvOpt oq2; oq2.ln = &b.ln2;
+            Act q2 = conv2d(c, b.q2, t1, nullptr, oq2);
+            const h16* kv = b.kv_cache + (size_t)sample0 * u.ctx_L * 2 * C;     // this lane's samples of the cached cross-attention K / V
+            Act o2 = attn(q2.p, C, (long long)T * C, kv, kv + C, 2 * C, (long long)u.ctx_L * 2 * C, n, T, u.ctx_L, b.heads);
+            ConvOpt or2; or2.res0 = &t1;
+            t2 = conv2d(c, b.o2, o2, nullptr, or2);
+        }
+        Act t3;
+        if (fuse >= 2) {
+            t3 = c.new_act(n, T, 1, C);
+            if (!c.dry()) {
+                FFBlockArgs fa;
+                fa.x = t2.p; fa.ln_g = b.ln3.g; fa.ln_b = b.ln3.b; fa.ln_eps = 1e-5f;
+                fa.W1 = b.ff1.w; fa.b1 = b.ff1.b; fa.W2 = b.ff2_packed; fa.bo = b.ff2.b; fa.res = t2.p; fa.out = t3.p; fa.P = n * T;
+                c.check(ladi_launch_ff_block(fa, c.st), "ff_block");
+            }
+        } else {
+            ConvOpt og; og.act = LADI_ACT_GEGLU; og.ln = &b.ln3;
+            Act gg = conv2d(c, b.ff1, t2, nullptr, og);
+            ConvOpt or3; or3.res0 = &t2;
+            t3 = conv2d(c, b.ff2, gg, nullptr, or3);
+        }
         Act xin = x; xin.h = T; xin.w = 1;
         Act outv = out; outv.h = T; outv.w = 1;
         ConvOpt oo; oo.res0 = &xin;

@@ -1,0 +1,740 @@
+// Fused transformer sub-blocks of the 64x48 level (C = 320) -- round 5.  Two kernels, one idea: a 32x32 MFMA accumulator block is the B operand
+// of the next product once the A side reads its rows as two 8-byte pieces (the k order of an accumulator block is a row permutation), so
+// chained projections never leave the registers:
+//   xattn_full_kernel   LayerNorm -> to_q -> 77-key cross-attention -> to_out + bias + residual   (BasicTransformerBlock attn2; replaces
+//                       linear_xs + flash_attn64<1,64,4> + linear_xs, two HBM round trips of a [P x 320] tensor)
+//   ff_fused_kernel     LayerNorm -> GEGLU (320 -> 2 x 1280) -> down-projection + bias + residual   (ff; replaces linear_xs GEGLU + the 1280 -> 320
+//                       projection and the [P x 1280] hidden tensor between them)
+// One wave per SIMD (the ten 32-channel output accumulator blocks live in AGPRs next to the 80-register pixel panel), one workgroup per
+// CU, so the weight ring alone has to cover the LDS-DMA round trip (4 / 6 slots).  Index arithmetic replayed on the CPU:
+// tools/experiments/next/xattn_full_emu.py, ff_fused_emu.py.  Operand packings (written once: pack_* kernels below):
+//   K tiles [n][5][96][68], V^T tiles [n][5][64][100] (zero padded), Wo [5][320][68], W2 [40][320][36]; W1 / b1 in the GEGLU packing.
+#include "common.h"
+#include "kernels.h"
+#include <cstdlib>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+// wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform; clamping down is conservative; the
+// counter has 6 bits)
+__device__ __forceinline__ void wait_vm_n(int n) {
+    switch (n < 48 ? n : 48) {
+        VM_CASE(1) VM_CASE(2) VM_CASE(3) VM_CASE(4) VM_CASE(5) VM_CASE(6) VM_CASE(7) VM_CASE(8) VM_CASE(9) VM_CASE(10) VM_CASE(11) VM_CASE(12)
+        VM_CASE(13) VM_CASE(14) VM_CASE(15) VM_CASE(16) VM_CASE(17) VM_CASE(18) VM_CASE(19) VM_CASE(20) VM_CASE(21) VM_CASE(22) VM_CASE(23)
+        VM_CASE(24) VM_CASE(25) VM_CASE(26) VM_CASE(27) VM_CASE(28) VM_CASE(29) VM_CASE(30) VM_CASE(31) VM_CASE(32) VM_CASE(33) VM_CASE(34)
+        VM_CASE(35) VM_CASE(36) VM_CASE(37) VM_CASE(38) VM_CASE(39) VM_CASE(40) VM_CASE(41) VM_CASE(42) VM_CASE(43) VM_CASE(44) VM_CASE(45)
+        VM_CASE(46) VM_CASE(47) VM_CASE(48)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+
+namespace xa {
+constexpr int C = 320, HEADS = 5, D = 64, NKP = 96, KLD = 68, VLD = 100;
+constexpr int KS = C / 16;                       // k16 steps of the Q projection
+constexpr int STAGE = 32 * C * 2;                // one weight stage: 32 rows x 640 B
+constexpr int W_DMA = STAGE / 16 / 256;          // 16-byte pieces per thread per stage (5)
+constexpr int KTILE = NKP * KLD * 2;             // 13 056 B
+constexpr int VTILE = D * VLD * 2;               // 12 800 B
+constexpr int KVBUF = 16384;                     // both tiles land in whole 4 KB DMA rounds
+constexpr int OLD = 68;                          // row stride of the packed Wo slices (halves)
+constexpr int OSTAGE = 160 * OLD * 2;            // half of a head's Wo slice: 160 output channels x 136 B = 21 760 B
+constexpr int O_DMA = 6;                         // ... lands in six 4 KB DMA rounds (the descriptor ends with the slice: the rest is zero)
+constexpr int SLOT = O_DMA * 4096;               // ring slot: the larger of the two stage kinds
+constexpr int PLD = 40;                          // halves per patch row (32 channels + 8 pad)
+constexpr int PATCH = 32 * PLD * 2;
+constexpr int NST = 4;                           // ring depth: ONE workgroup per CU, nobody else covers a stage's round trip (a stage is consumed
+                                                 // in ~0.3 us): three stages (~70 KB) in flight; the K / V^T tiles are single-buffered
+constexpr int NSTAGE = 4 * HEADS;
+constexpr int SMEM = NST * SLOT + 2 * KVBUF + 4 * PATCH;
+
+__global__ __launch_bounds__(256, 1) void xattn_full_kernel(const XAttnBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    char* kbuf = smem + NST * SLOT;              // [KVBUF]
+    char* vbuf = kbuf + KVBUF;                   // [KVBUF]
+    char* patch_base = vbuf + KVBUF;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int p0 = blockIdx.x * 128 + wave * 32;
+    const int n = (blockIdx.x * 128) / a.T;      // a workgroup's 128 pixels lie in one sample (T % 128 == 0)
+
+    // ---- weight DMA (linear_xs.hip): LDS position i = j*256 + tid (16-byte units) -> row i/40, physical chunk i%40, XOR swizzle on the source
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.Wq), 0, (unsigned)(C * C * 2), 0x00020000);
+    unsigned wrel[W_DMA];
+#pragma unroll
+    for (int j = 0; j < W_DMA; ++j) {
+        const int i = j * 256 + tid;
+        const int row = i / (C / 8), cph = i - row * (C / 8);
+        const int c = cph ^ ((row >> 1) & 7);
+        wrel[j] = (unsigned)((row * C + c * 8) * 2);
+    }
+    int vm_issued = 0;                           // running count of this wave's VMEM operations (wave-uniform)
+    // stage (h, kind): kind 0 / 1 = rows [64 h + 32 kind, + 32) of Wq (swizzled, 5 pieces per thread); kind 2 / 3 = output channels
+    // [160 (kind - 2), + 160) of head h's packed Wo slice (linear, 6 rounds)
+    auto issue_stage = [&](int t, int slot) {    // stage t = (head t / 4, kind t % 4)
+        const int h = t >> 2, kind = t & 3;
+        char* dst = ring + slot * SLOT + wave * 1024;
+        if (kind < 2) {
+#pragma unroll
+            for (int j = 0; j < W_DMA; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + j * 4096), 16, wrel[j] + (unsigned)((2 * h + kind) * STAGE), 0, 0, 0);
+            vm_issued += W_DMA;
+        } else {
+            const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<h16*>(a.Wo) + ((size_t)h * C + (kind - 2) * 160) * OLD, 0, (unsigned)OSTAGE, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < O_DMA; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rso, (lds_ptr_t)(dst + j * 4096), 16, (unsigned)((j * 256 + tid) * 16), 0, 0, 0);
+            vm_issued += O_DMA;
+        }
+    };
+    // ---- K / V^T tiles of head h: linear copies, 4 rounds of 256 x 16 B each; the descriptors end with the tile, the rest reads as zero
+    auto issue_kv = [&](int h) {
+        const size_t g = (size_t)n * HEADS + h;
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.Kp) + g * (NKP * KLD), 0, (unsigned)KTILE, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.Vt) + g * (D * VLD), 0, (unsigned)VTILE, 0x00020000);
+        char* kd = kbuf + wave * 1024;
+        char* vd = vbuf + wave * 1024;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(kd + r * 4096), 16, (unsigned)((r * 256 + tid) * 16), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(vd + r * 4096), 16, (unsigned)((r * 256 + tid) * 16), 0, 0, 0);
+        }
+        vm_issued += 8;
+    };
+
+    // ---- the wave's pixel panel as MFMA B fragments: lane = pixel l31, k half hh
+    h16x8 xf[KS];
+    {
+        const h16* xp = a.x + (size_t)(p0 + l31) * C + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const h16x8*>(xp + ks * 16);
+    }
+    // marks: mk[i] = value of vm_issued right after stage (current + i) was issued; the ring keeps NST - 1 stages in flight
+    int mk[NST - 1];
+    issue_kv(0);
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) { issue_stage(i, i); mk[i] = vm_issued; }
+    int rd_slot = 0, wr_slot = NST - 1;          // slot of the stage being multiplied / of the next stage to issue
+    // ---- LayerNorm of the panel (same arithmetic and rounding point as layernorm_kernel / linear_xs PRE = 1)
+    {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        auto pin = [](h16x8& v) {
+            i32x4 t = __builtin_bit_cast(i32x4, v);
+            asm volatile("" : "+v"(t));
+            v = __builtin_bit_cast(h16x8, t);
+        };
+        const float invK = 1.f / (float)C;
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            pin(xf[ks]);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t += (float)xf[ks][e];
+            s += t;
+            asm volatile("" : "+v"(s));
+        }
+        s += __shfl_xor(s, 32);
+        const float mean = s * invK;
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            pin(xf[ks]);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)xf[ks][e] - mean; t += d * d; }
+            q += t;
+            asm volatile("" : "+v"(q));
+        }
+        q += __shfl_xor(q, 32);
+        const float rstd = rsqrtf(q * invK + a.ln_eps);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            pin(xf[ks]);
+            const h16x8 g = *reinterpret_cast<const h16x8*>(a.ln_g + ks * 16 + hh * 8);
+            const h16x8 b = *reinterpret_cast<const h16x8*>(a.ln_b + ks * 16 + hh * 8);
+            h16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)xf[ks][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+            xf[ks] = o;
+            pin(xf[ks]);
+        }
+    }
+
+    // swizzled A-fragment addresses of a weight stage (linear_xs.hip)
+    const int tsw = hh ^ ((l31 >> 1) & 7);
+    int aoff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) aoff[m] = l31 * (C * 2) + ((tsw ^ (2 * m)) << 4);
+
+    const float qscale = a.scale * 1.4426950408889634f;
+    h16* patch = reinterpret_cast<h16*>(patch_base + wave * PATCH);
+
+    f32x16 yacc[10];                             // out^T: ten 32-channel blocks x 32 pixels
+#pragma unroll
+    for (int ob = 0; ob < 10; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.f;
+
+    for (int h = 0; h < HEADS; ++h) {
+        f32x16 qacc[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qacc[b][r] = 0.f;
+        h16x8 of[4];                             // O_h^T / l as B fragments (filled by the attention between stage kinds 1 and 2)
+        static_for<0, 4>([&](auto Kc) {
+            constexpr int kind = decltype(Kc)::value;
+            const int s = 4 * h + kind;
+            if (s == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): panel, LayerNorm vectors, first K / V^T tile, the prologue's stages
+            else wait_vm_n(vm_issued - mk[0]);                  // stage s has landed; the NST - 2 stages behind it may stay in flight
+            asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+            for (int i = 0; i + 1 < NST - 1; ++i) mk[i] = mk[i + 1];
+            // the K / V^T buffers are free once every wave is past the attention of head h (it sits in the kind-1 step, i.e. before this
+            // barrier when kind == 2); the next head's tiles are issued AHEAD of stage s + NST - 1 = (h + 1, kind 1), whose wait -- at the
+            // step that runs the attention of head h + 1 -- therefore covers them (VMEM retires in order), and that step's barrier
+            // publishes every wave's part
+            if (kind == 2 && h + 1 < HEADS) issue_kv(h + 1);
+            if (s + NST - 1 < NSTAGE) { issue_stage(s + NST - 1, wr_slot); mk[NST - 2] = vm_issued; }    // into the slot stage s - 1 just left
+            wr_slot = (wr_slot + 1 == NST) ? 0 : wr_slot + 1;
+            const char* sW = ring + rd_slot * SLOT;
+            rd_slot = (rd_slot + 1 == NST) ? 0 : rd_slot + 1;
+            if constexpr (kind < 2) {
+                // ---- Q_h^T block `kind` = Wq rows x X^T
+#pragma unroll
+                for (int k16 = 0; k16 < KS; ++k16) {
+                    const h16x8 af = *reinterpret_cast<const h16x8*>(sW + aoff[k16 & 3] + (((2 * k16) & ~7) << 4));
+                    qacc[kind] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[k16], qacc[kind], 0, 0, 0);
+                }
+            } else {
+                // ---- out^T blocks 5 (kind - 2) .. + 5  +=  Wo slice rows x O_h^T (k = d, in accumulator-row order)
+                const h16* wo = reinterpret_cast<const h16*>(sW);
+#pragma unroll
+                for (int jb = 0; jb < 5; ++jb) {
+#pragma unroll
+                    for (int ks2 = 0; ks2 < 4; ++ks2) {
+                        const h16* rowp = wo + (32 * jb + l31) * OLD + 32 * (ks2 >> 1) + 16 * (ks2 & 1) + 4 * hh;
+                        const h16x4 lo = *reinterpret_cast<const h16x4*>(rowp);
+                        const h16x4 hi = *reinterpret_cast<const h16x4*>(rowp + 8);
+                        const h16x8 af = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        yacc[5 * (kind - 2) + jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, of[ks2], yacc[5 * (kind - 2) + jb], 0, 0, 0);
+                    }
+                }
+            }
+            if constexpr (kind == 1) {
+                // ================= attention of head h (its K / V^T tiles were complete at this step's barrier) =================
+                const h16* kt = reinterpret_cast<const h16*>(kbuf);
+                const h16* vt = reinterpret_cast<const h16*>(vbuf);
+                // ---- Q fragments: the accumulator blocks, rounded as the stand-alone path rounds them (fp16 Q, then fp16(Q * scale * log2 e))
+                h16x8 qf[4];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const h16 q16 = (h16)qacc[b][4 * (2 * gp + (i >> 2)) + (i & 3)];
+                            qf[b * 2 + gp][i] = (h16)((float)q16 * qscale);
+                        }
+                // ---- S^T = K_h Q_h: 3 key blocks x 4 k steps
+                f32x16 sc[3];
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const h16* rowp = kt + (32 * kb + l31) * KLD + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * hh;
+                        const h16x4 lo = *reinterpret_cast<const h16x4*>(rowp);
+                        const h16x4 hi = *reinterpret_cast<const h16x4*>(rowp + 8);
+                        const h16x8 af = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, qf[ks], sc[kb], 0, 0, 0);
+                    }
+                }
+                // ---- softmax over the keys of this lane's query column (rows 8g + 4hh + e of each block here, the rest in lane ^ 32)
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * kb + 8 * (r >> 2) + 4 * hh + (r & 3);
+                        const float v = key < a.nk ? sc[kb][r] : -3.0e38f;
+                        sc[kb][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float l = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(sc[kb][r] - mx);
+                        sc[kb][r] = p;
+                        l += p;
+                    }
+                l += __shfl_xor(l, 32);
+                h16x8 pf[6];
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) pf[kb * 2 + gp][i] = (h16)sc[kb][4 * (2 * gp + (i >> 2)) + (i & 3)];
+                // ---- O_h^T = V_h^T P: 2 d blocks x 6 k steps
+                f32x16 oa[2];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oa[db][r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks) {
+                        const h16* rowp = vt + (32 * db + l31) * VLD + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * hh;
+                        const h16x4 lo = *reinterpret_cast<const h16x4*>(rowp);
+                        const h16x4 hi = *reinterpret_cast<const h16x4*>(rowp + 8);
+                        const h16x8 af = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        oa[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, pf[ks], oa[db], 0, 0, 0);
+                    }
+                }
+                // ---- O_h^T / l, fp16: B fragments of the output projection
+                const float inv = __builtin_amdgcn_rcpf(l);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) of[db * 2 + gp][i] = (h16)(oa[db][4 * (2 * gp + (i >> 2)) + (i & 3)] * inv);
+            }
+        });
+    }
+
+    // ---- epilogue (linear_xs MODE 1 rounding): fp16(acc + bias) + residual -> fp16, transposed through the wave's patch, 64-byte row segments
+    {
+        const int rb_row2 = lane >> 2, rb_chunk2 = lane & 3;
+        static_for<0, 10>([&](auto Oc) {
+            constexpr int ob = decltype(Oc)::value;
+            h16x8 rr[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                rr[r] = *reinterpret_cast<const h16x8*>(a.res + (size_t)(p0 + rb_row2 + 16 * r) * C + ob * 32 + rb_chunk2 * 8);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const h16x4 b4 = *reinterpret_cast<const h16x4*>(a.bo + ob * 32 + 8 * g + 4 * hh);
+                h16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (h16)(yacc[ob][4 * g + e] + (float)b4[e]);
+                *reinterpret_cast<h16x4*>(patch + l31 * PLD + 8 * g + 4 * hh) = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = rb_row2 + 16 * r;
+                const h16x8 v = *reinterpret_cast<const h16x8*>(patch + row * PLD + rb_chunk2 * 8);
+                h16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (h16)((float)v[e] + (float)rr[r][e]);
+                *reinterpret_cast<h16x8*>(a.out + (size_t)(p0 + row) * C + ob * 32 + rb_chunk2 * 8) = o;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        });
+    }
+}
+
+}  // namespace xa
+
+namespace ffn {
+constexpr int C = 320, HID = 1280, NB = HID / 32;
+constexpr int KS = C / 16;                       // k16 steps of the up-projection
+constexpr int STAGE = 32 * C * 2;                // one up-projection stage: 32 rows x 640 B
+constexpr int W_DMA = STAGE / 16 / 256;          // 16-byte pieces per thread per stage (5)
+constexpr int DLD = 36;                          // row stride of a packed W2 slice (halves)
+constexpr int DSTAGE = C * DLD * 2;              // 320 output channels x 72 B = 23 040 B
+constexpr int D_DMA = 6;                         // ... lands in six 4 KB DMA rounds (the descriptor ends with the slice: the rest is zero)
+constexpr int SLOT = D_DMA * 4096;
+constexpr int PLD = 40;                          // halves per patch row (32 channels + 8 pad)
+constexpr int PATCH = 32 * PLD * 2;
+constexpr int BIAS1 = 2 * HID * 2;               // the up-projection's bias vector (5 KB)
+constexpr int NST = 6;                           // ring depth: at ONE workgroup per CU nobody else covers a stage's round trip -- a stage is
+                                                 // consumed in ~0.3 us (20 MFMAs), so five stages (~110 KB) have to be in flight
+constexpr int NSTAGE = 3 * NB;
+constexpr int SMEM = NST * SLOT + BIAS1 + 4 * PATCH;
+
+// PIPE = 1: the GEGLU arithmetic of hidden block hb - 1 (320 VALU instructions per wave) is placed next to the u / g MFMAs of block hb (a
+// second pair of accumulator blocks), and the down-projection of a block runs one block late: at one wave per SIMD no other wave hides the
+// VALU work, the wave has to overlap it with its own MFMAs.  Ring order: u0 g0 | u1 g1 W2(0) | u2 g2 W2(1) | ... | W2(NB-1).
+template <int PIPE>
+__global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    h16* bias_s = reinterpret_cast<h16*>(smem + NST * SLOT);     // [2 HID]
+    char* patch_base = smem + NST * SLOT + BIAS1;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int p0 = blockIdx.x * 128 + wave * 32;
+
+    // ---- up-projection DMA (linear_xs.hip): LDS position i = j*256 + tid (16-byte units) -> row i/40, physical chunk i%40, XOR swizzle on the source
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.W1), 0, (unsigned)(2 * HID * C * 2), 0x00020000);
+    unsigned wrel[W_DMA];
+#pragma unroll
+    for (int j = 0; j < W_DMA; ++j) {
+        const int i = j * 256 + tid;
+        const int row = i / (C / 8), cph = i - row * (C / 8);
+        const int c = cph ^ ((row >> 1) & 7);
+        wrel[j] = (unsigned)((row * C + c * 8) * 2);
+    }
+    int vm_issued = 0;                           // running count of this wave's VMEM operations (wave-uniform)
+    // stage (hb, kind): kind 0 / 1 = the u / g rows of hidden block hb (32-row block 2 hb + kind of the packed W1; swizzled, 5 pieces per
+    // thread); kind 2 = the packed W2 slice of hidden block hb (linear, 6 rounds)
+    auto issue_stage = [&](int t, int slot) {    // PIPE 0: stage t = (hidden block t / 3, kind t % 3); PIPE 1: the order above
+        int hb, kind;
+        if (!PIPE) { hb = t / 3; kind = t - 3 * hb; }
+        else if (t < 2) { hb = 0; kind = t; }
+        else {
+            const int grp = (t - 2) / 3, k = (t - 2) - 3 * grp;
+            if (grp == NB - 1) { hb = NB - 1; kind = 2; }
+            else if (k < 2) { hb = grp + 1; kind = k; }
+            else { hb = grp; kind = 2; }
+        }
+        char* dst = ring + slot * SLOT + wave * 1024;
+        if (kind < 2) {
+#pragma unroll
+            for (int j = 0; j < W_DMA; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(dst + j * 4096), 16, wrel[j] + (unsigned)((2 * hb + kind) * STAGE), 0, 0, 0);
+            vm_issued += W_DMA;
+        } else {
+            const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.W2) + (size_t)hb * C * DLD, 0, (unsigned)DSTAGE, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < D_DMA; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr_t)(dst + j * 4096), 16, (unsigned)((j * 256 + tid) * 16), 0, 0, 0);
+            vm_issued += D_DMA;
+        }
+    };
+
+    // ---- the wave's pixel panel as MFMA B fragments: lane = pixel l31, k half hh
+    h16x8 xf[KS];
+    {
+        const h16* xp = a.x + (size_t)(p0 + l31) * C + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const h16x8*>(xp + ks * 16);
+    }
+    // marks: mk[i] = value of vm_issued right after stage (current + i) was issued; the ring keeps NST - 1 stages in flight
+    int mk[NST - 1];
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) { issue_stage(i, i); mk[i] = vm_issued; }
+    int rd_slot = 0, wr_slot = NST - 1;          // slot of the stage being multiplied / of the next stage to issue
+    // ---- LayerNorm of the panel (same arithmetic and rounding point as layernorm_kernel / linear_xs PRE = 1)
+    {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        auto pin = [](h16x8& v) {
+            i32x4 t = __builtin_bit_cast(i32x4, v);
+            asm volatile("" : "+v"(t));
+            v = __builtin_bit_cast(h16x8, t);
+        };
+        const float invK = 1.f / (float)C;
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            pin(xf[ks]);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t += (float)xf[ks][e];
+            s += t;
+            asm volatile("" : "+v"(s));
+        }
+        s += __shfl_xor(s, 32);
+        const float mean = s * invK;
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            pin(xf[ks]);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)xf[ks][e] - mean; t += d * d; }
+            q += t;
+            asm volatile("" : "+v"(q));
+        }
+        q += __shfl_xor(q, 32);
+        const float rstd = rsqrtf(q * invK + a.ln_eps);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            pin(xf[ks]);
+            const h16x8 g = *reinterpret_cast<const h16x8*>(a.ln_g + ks * 16 + hh * 8);
+            const h16x8 b = *reinterpret_cast<const h16x8*>(a.ln_b + ks * 16 + hh * 8);
+            h16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)xf[ks][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+            xf[ks] = o;
+            pin(xf[ks]);
+        }
+    }
+
+    // ---- the up-projection's bias -> LDS (its loads are drained by the vmcnt(0) in front of stage 0)
+    for (int i = tid; i < 2 * HID; i += 256) bias_s[i] = a.b1[i];
+
+    // swizzled A-fragment addresses of an up-projection stage (linear_xs.hip)
+    const int tsw = hh ^ ((l31 >> 1) & 7);
+    int aoff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) aoff[m] = l31 * (C * 2) + ((tsw ^ (2 * m)) << 4);
+
+    h16* patch = reinterpret_cast<h16*>(patch_base + wave * PATCH);
+
+    f32x16 yacc[10];                             // out^T: ten 32-channel blocks x 32 pixels
+#pragma unroll
+    for (int ob = 0; ob < 10; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.f;
+
+    if constexpr (!PIPE) {
+        for (int hb = 0; hb < NB; ++hb) {
+            f32x16 ug[2];
+    #pragma unroll
+            for (int b = 0; b < 2; ++b)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) ug[b][r] = 0.f;
+            h16x8 hf[2];                             // the hidden block as B fragments (filled after the g stage)
+            static_for<0, 3>([&](auto Kc) {
+                constexpr int kind = decltype(Kc)::value;
+                const int s = 3 * hb + kind;
+                if (s == 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): panel, LayerNorm vectors, bias, the prologue's stages
+                else wait_vm_n(vm_issued - mk[0]);                  // stage s has landed; the NST - 2 stages behind it may stay in flight
+                asm volatile("s_barrier" ::: "memory");
+    #pragma unroll
+                for (int i = 0; i + 1 < NST - 1; ++i) mk[i] = mk[i + 1];
+                if (s + NST - 1 < NSTAGE) { issue_stage(s + NST - 1, wr_slot); mk[NST - 2] = vm_issued; }    // into the slot stage s - 1 just left
+                wr_slot = (wr_slot + 1 == NST) ? 0 : wr_slot + 1;
+                const char* sW = ring + rd_slot * SLOT;
+                rd_slot = (rd_slot + 1 == NST) ? 0 : rd_slot + 1;
+                if constexpr (kind < 2) {
+    #pragma unroll
+                    for (int k16 = 0; k16 < KS; ++k16) {
+                        const h16x8 af = *reinterpret_cast<const h16x8*>(sW + aoff[k16 & 3] + (((2 * k16) & ~7) << 4));
+                        ug[kind] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[k16], ug[kind], 0, 0, 0);
+                    }
+                } else {
+                    // ---- out^T += W2 slice x h (k = hidden channel inside the block, in accumulator-row order)
+                    const h16* wd = reinterpret_cast<const h16*>(sW);
+    #pragma unroll
+                    for (int ob = 0; ob < 10; ++ob) {
+    #pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            const h16* rowp = wd + (32 * ob + l31) * DLD + 16 * gp + 4 * hh;
+                            const h16x4 lo = *reinterpret_cast<const h16x4*>(rowp);
+                            const h16x4 hi = *reinterpret_cast<const h16x4*>(rowp + 8);
+                            const h16x8 af = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            yacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, hf[gp], yacc[ob], 0, 0, 0);
+                        }
+                    }
+                }
+                if constexpr (kind == 1) {
+                    // ---- h = fp16((u + bu) * gelu(g + bg)): the GEGLU epilogue of linear_xs MODE 2, kept in registers as B fragments
+                    const h16* bu = bias_s + (2 * hb) * 32;
+                    const h16* bg = bu + 32;
+    #pragma unroll
+                    for (int gp = 0; gp < 2; ++gp)
+    #pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int r0 = 4 * (2 * gp + q);                  // first accumulator register of this group of four
+                            const int row0 = 8 * (2 * gp + q) + 4 * hh;       // its row inside the 32-channel block
+                            const h16x4 bu4 = *reinterpret_cast<const h16x4*>(bu + row0);
+                            const h16x4 bg4 = *reinterpret_cast<const h16x4*>(bg + row0);
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                hf[gp][4 * q + e] = (h16)((ug[0][r0 + e] + (float)bu4[e]) * gelu_f(ug[1][r0 + e] + (float)bg4[e]));
+                        }
+                }
+            });
+        }
+    } else {
+        static_assert(NB % 2 == 0, "the block loop is unrolled by two (two pairs of accumulator blocks with compile-time names)");
+        int step = 0;
+        auto begin = [&]() -> const char* {       // hand-over of the next ring stage (same protocol as the plain loop)
+            if (step == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else wait_vm_n(vm_issued - mk[0]);
+            asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+            for (int i = 0; i + 1 < NST - 1; ++i) mk[i] = mk[i + 1];
+            if (step + NST - 1 < NSTAGE) { issue_stage(step + NST - 1, wr_slot); mk[NST - 2] = vm_issued; }
+            wr_slot = (wr_slot + 1 == NST) ? 0 : wr_slot + 1;
+            const char* sW = ring + rd_slot * SLOT;
+            rd_slot = (rd_slot + 1 == NST) ? 0 : rd_slot + 1;
+            ++step;
+            return sW;
+        };
+        auto up = [&](const char* sW, f32x16& acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int k16 = 0; k16 < KS; ++k16) {
+                const h16x8 af = *reinterpret_cast<const h16x8*>(sW + aoff[k16 & 3] + (((2 * k16) & ~7) << 4));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[k16], acc, 0, 0, 0);
+            }
+        };
+        auto geglu_half = [&](const f32x16& u, const f32x16& g, int hb, int gp, h16x8& dst) {
+            const h16* bu = bias_s + (2 * hb) * 32;
+            const h16* bg = bu + 32;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r0 = 4 * (2 * gp + q), row0 = 8 * (2 * gp + q) + 4 * hh;
+                const h16x4 bu4 = *reinterpret_cast<const h16x4*>(bu + row0);
+                const h16x4 bg4 = *reinterpret_cast<const h16x4*>(bg + row0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[4 * q + e] = (h16)((u[r0 + e] + (float)bu4[e]) * gelu_f(g[r0 + e] + (float)bg4[e]));
+            }
+        };
+        auto down = [&](const char* sW, const h16x8 (&hf)[2]) {
+            const h16* wd = reinterpret_cast<const h16*>(sW);
+#pragma unroll
+            for (int ob = 0; ob < 10; ++ob)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const h16* rowp = wd + (32 * ob + l31) * DLD + 16 * gp + 4 * hh;
+                    const h16x4 lo = *reinterpret_cast<const h16x4*>(rowp);
+                    const h16x4 hi = *reinterpret_cast<const h16x4*>(rowp + 8);
+                    const h16x8 af = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    yacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, hf[gp], yacc[ob], 0, 0, 0);
+                }
+        };
+        f32x16 uA, gA, uB, gB;
+        h16x8 hf[2];
+        up(begin(), uA);
+        up(begin(), gA);
+        for (int hb = 1; hb < NB; hb += 2) {
+            // block hb into (uB, gB) next to the GEGLU of block hb - 1 from (uA, gA)
+            { const char* sW = begin(); up(sW, uB); geglu_half(uA, gA, hb - 1, 0, hf[0]); }
+            { const char* sW = begin(); up(sW, gB); geglu_half(uA, gA, hb - 1, 1, hf[1]); }
+            down(begin(), hf);
+            if (hb + 1 < NB) {
+                { const char* sW = begin(); up(sW, uA); geglu_half(uB, gB, hb, 0, hf[0]); }
+                { const char* sW = begin(); up(sW, gA); geglu_half(uB, gB, hb, 1, hf[1]); }
+                down(begin(), hf);
+            }
+        }
+        geglu_half(uB, gB, NB - 1, 0, hf[0]);
+        geglu_half(uB, gB, NB - 1, 1, hf[1]);
+        down(begin(), hf);
+    }
+
+    // ---- epilogue (linear_xs MODE 1 rounding): fp16(acc + bias) + residual -> fp16, transposed through the wave's patch, 64-byte row segments
+    {
+        const int rb_row2 = lane >> 2, rb_chunk2 = lane & 3;
+        static_for<0, 10>([&](auto Oc) {
+            constexpr int ob = decltype(Oc)::value;
+            h16x8 rr[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                rr[r] = *reinterpret_cast<const h16x8*>(a.res + (size_t)(p0 + rb_row2 + 16 * r) * C + ob * 32 + rb_chunk2 * 8);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const h16x4 b4 = *reinterpret_cast<const h16x4*>(a.bo + ob * 32 + 8 * g + 4 * hh);
+                h16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (h16)(yacc[ob][4 * g + e] + (float)b4[e]);
+                *reinterpret_cast<h16x4*>(patch + l31 * PLD + 8 * g + 4 * hh) = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = rb_row2 + 16 * r;
+                const h16x8 v = *reinterpret_cast<const h16x8*>(patch + row * PLD + rb_chunk2 * 8);
+                h16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (h16)((float)v[e] + (float)rr[r][e]);
+                *reinterpret_cast<h16x8*>(a.out + (size_t)(p0 + row) * C + ob * 32 + rb_chunk2 * 8) = o;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        });
+    }
+}
+
+}  // namespace ffn
+
+// ---- operand packing (step-invariant / load-time)
+// kv [n][L][2C] (K | V as the kv projection writes them) -> K tiles [n][H][96][68] and V^T tiles [n][H][64][100], zero padded
+__global__ void pack_kv_tiles_kernel(const h16* __restrict__ kv, int n, int L, int C, int H, h16* __restrict__ kp, h16* __restrict__ vt) {
+    const size_t g = blockIdx.x;                   // (sample, head)
+    const int s = (int)(g / H), h = (int)(g % H);
+    h16* kt = kp + g * (xa::NKP * xa::KLD);
+    h16* vtile = vt + g * (xa::D * xa::VLD);
+    for (int i = threadIdx.x; i < xa::NKP * xa::KLD; i += blockDim.x) {
+        const int k = i / xa::KLD, d = i - k * xa::KLD;
+        kt[i] = (k < L && d < xa::D) ? kv[((size_t)s * L + k) * 2 * C + h * xa::D + d] : (h16)0.f;
+    }
+    for (int i = threadIdx.x; i < xa::D * xa::VLD; i += blockDim.x) {
+        const int d = i / xa::VLD, k = i - d * xa::VLD;
+        vtile[i] = (k < L) ? kv[((size_t)s * L + k) * 2 * C + C + h * xa::D + d] : (h16)0.f;
+    }
+}
+// W [rows][cols] row-major -> [cols / blk][rows][ld] with W[q][blk * j + i] at [j][q][i] (i < blk), zero padded to ld
+__global__ void pack_col_blocks_kernel(const h16* __restrict__ W, int rows, int cols, int blk, int ld, h16* __restrict__ out) {
+    const size_t total = (size_t)(cols / blk) * rows * ld;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld); const size_t r = i / ld;
+        const int q = (int)(r % rows), j = (int)(r / rows);
+        out[i] = c < blk ? W[(size_t)q * cols + (size_t)j * blk + c] : (h16)0.f;
+    }
+}
+
+}  // namespace
+
+size_t ladi_xf_kp_elems(int n) { return (size_t)n * xa::HEADS * xa::NKP * xa::KLD; }
+size_t ladi_xf_vt_elems(int n) { return (size_t)n * xa::HEADS * xa::D * xa::VLD; }
+size_t ladi_xf_wo_packed_elems() { return (size_t)xa::HEADS * xa::C * xa::OLD; }
+size_t ladi_xf_w2_packed_elems() { return (size_t)ffn::NB * ffn::C * ffn::DLD; }
+
+int ladi_launch_pack_kv_tiles(const h16* kv, int n, int L, int C, h16* kp, h16* vt, hipStream_t st) {
+    if (C != xa::C || L < 1 || L > xa::NKP || n < 1) return -1;
+    hipLaunchKernelGGL(pack_kv_tiles_kernel, dim3((unsigned)(n * xa::HEADS)), dim3(256), 0, st, kv, n, L, C, xa::HEADS, kp, vt);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+int ladi_launch_pack_wo(const h16* Wo, h16* out, hipStream_t st) {      // [320][320] -> [5][320][68]
+    hipLaunchKernelGGL(pack_col_blocks_kernel, dim3(256), dim3(256), 0, st, Wo, xa::C, xa::C, xa::D, xa::OLD, out);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+int ladi_launch_pack_w2(const h16* W2, h16* out, hipStream_t st) {      // [320][1280] -> [40][320][36]
+    hipLaunchKernelGGL(pack_col_blocks_kernel, dim3(256), dim3(256), 0, st, W2, ffn::C, ffn::HID, 32, ffn::DLD, out);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+bool ladi_xf_fused_eligible(int C, int heads, int T, int L) { return C == xa::C && heads == xa::HEADS && T > 0 && (T % 128) == 0 && L >= 1 && L <= xa::NKP; }
+
+int ladi_launch_xattn_block(const XAttnBlockArgs& a, hipStream_t st) {
+    if (a.P <= 0 || (a.P % 128) || a.T <= 0 || (a.T % 128) || (a.P % a.T) || a.nk < 1 || a.nk > xa::NKP) return -1;
+    if (((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.Wq | (uintptr_t)a.Kp | (uintptr_t)a.Vt | (uintptr_t)a.Wo) & 15) return -4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(xa::xattn_full_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, xa::SMEM) != hipSuccess) return -10;
+        attr = true;
+    }
+    hipLaunchKernelGGL(xa::xattn_full_kernel, dim3((unsigned)(a.P / 128)), dim3(256), xa::SMEM, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
+int ladi_launch_ff_block(const FFBlockArgs& a, hipStream_t st) {
+    if (a.P <= 0 || (a.P % 128)) return -1;
+    if (((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.W1 | (uintptr_t)a.W2) & 15) return -4;
+    const char* e = getenv("LADI_FF_PIPE");         // read per call: one process can run both loop forms (tests, A/B)
+    const bool pipe = !(e && e[0] == '0');
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn::ff_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, ffn::SMEM) != hipSuccess) return -10;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn::ff_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ffn::SMEM) != hipSuccess) return -10;
+        attr = true;
+    }
+    if (pipe) hipLaunchKernelGGL(ffn::ff_fused_kernel<1>, dim3((unsigned)(a.P / 128)), dim3(256), ffn::SMEM, st, a);
+    else hipLaunchKernelGGL(ffn::ff_fused_kernel<0>, dim3((unsigned)(a.P / 128)), dim3(256), ffn::SMEM, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}

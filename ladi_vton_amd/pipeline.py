@@ -40,7 +40,7 @@ class StableDiffusionTryOnePipeline:
         self._tryon = None
         self.last_stage_ms = None
         self.trace_evals = 0          # > 0: the next fused runs record per-evaluation noise_pred / latents into self.last_trace
-        self.lanes = None             # sample-group lanes of the fused loop's UNet forward (None: library default, LADI_UNET_LANES or 2)
+        self.lanes = None             # sample-group lanes of the fused loop's UNet forward (None: library default, LADI_UNET_LANES or 1)
 
     def to(self, *a, **k):
         return self

@@ -56,6 +56,8 @@ class NativeCLIPTextEncoder(_Shim):
         # `tokenized_text.to(device)`, inference.py:291): they stay there -- no device -> host copy, hence no synchronisation
         on_dev = input_ids.is_cuda
         ids = input_ids.reshape(-1, input_ids.shape[-1]).to(dtype=torch.int32).contiguous()
+        if on_dev and ids.device != self.device:
+            ids = ids.to(self.device)          # ids on ANOTHER GPU: their pointer means nothing to this encoder's device
         B, T = ids.shape
         H = self.cfg["hidden"]
         we = None

@@ -68,6 +68,9 @@ def clip_pixels(cloth):
     """src/inference.py:267-272: (cloth + 1) / 2 -> resize 224 (bilinear, antialias) -> CLIP mean / std normalisation; rounded to fp16, the
     dtype the vision encoder receives in the reference (`.to(weight_dtype)`)"""
     img = F.interpolate((cloth + 1) / 2, size=(224, 224), mode="bilinear", antialias=True, align_corners=False).clamp(0, 1)
+    # `processor(images=input_image)` (transformers 4.27.3 CLIPImageProcessor): resize -> to_pil_image = (x * 255).astype(uint8), a truncation;
+    # the 224x224 image passes the PIL resize / centre crop unchanged and is rescaled by 1 / 255 before the normalisation
+    img = torch.floor(img * 255.0) / 255.0
     mean = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(CLIP_STD).view(1, 3, 1, 1)
     return ((img - mean) / std).half().float()

@@ -16,3 +16,16 @@ def pytest_configure(config):
 def lib():
     from ladi_vton_amd import _lib
     return _lib.load()
+
+
+def pytest_sessionstart(session):
+    """a GPU session starts its parity record from scratch (tests/util.py record_parity): the committed profiles/r05_parity.json is one run"""
+    import time
+    os.environ["LADI_PYTEST_SESSION"] = time.strftime("%Y%m%dT%H%M%S")
+    markexpr = getattr(session.config.option, "markexpr", "") or ""
+    if "gpu" in markexpr and "not gpu" not in markexpr:
+        from tests import util as U
+        try:
+            os.remove(U.parity_path())
+        except OSError:
+            pass

@@ -822,3 +822,31 @@ def test_fragment_chain_emulations_of_the_fused_prototypes():
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "next", name)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (name, r.stdout[-400:], r.stderr[-400:])
         assert "e-1" in r.stdout, (name, r.stdout)      # 1e-15-class agreement printed by each script
+
+
+# keys of the parity record the documents quote numbers from (README.md); tools/commit_parity.py
+# refuses a record that lacks one of them
+PARITY_KEYS_CITED = ["unet_forward_full_64x48_n16_vs_oracle", "config2_chain_B2_20_pndm_vs_oracle", "tryon_512x384_50_pndm_B8_vs_oracle",
+                     "tryon_1024x768_100_ddim_B1_vs_oracle"]
+
+
+def test_committed_parity_record_is_one_run_and_holds_every_cited_key():
+    """profiles/r05_parity.json is ONE full `pytest -m gpu` run on one binary (tests/util.py record_parity stamps the library digest and the
+    session id; tests/conftest.py starts every GPU session from an empty record) and holds every key the documents cite -- explicitly listed
+    above, plus every `..._vs_oracle` key a document names in back-ticks (the round-4 file was a 3-key fragment that lacked the
+    key BASELINE.md quoted)."""
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "r05_parity.json")
+    if not os.path.exists(path):
+        pytest.skip("no round-5 parity record committed yet")
+    blob = json.load(open(path))
+    assert re.fullmatch(r"[0-9a-f]{64}", blob.get("_library_digest", "")), "the record names the library it was taken on"
+    assert blob.get("_session"), "the record names its pytest session"
+    cited = set(PARITY_KEYS_CITED)
+    for doc in ("DESIGN.md", "BASELINE.md", "README.md", os.path.join("profiles", "README.md")):
+        cited.update(re.findall(r"`([a-z0-9_]+_vs_oracle)`", open(os.path.join(root, doc)).read()))
+    missing = sorted(k for k in cited if k not in blob)
+    assert not missing, missing
+    assert len([k for k in blob if not k.startswith("_")]) >= 12, "a full GPU run records every measured tolerance, not a fragment"

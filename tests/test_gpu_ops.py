@@ -92,6 +92,82 @@ def test_linear_x_stationary_geglu(cfg, C, Qh, T):
     assert U.rel_l2(y.float().cpu().reshape(T, Qh), ref) < TOL
 
 
+@pytest.mark.parametrize("n,T,L", [(2, 256, 77), (1, 3072, 77), (3, 128, 96), (2, 128, 5)])
+def test_fused_cross_attention_block(n, T, L):
+    """attn2 of a BasicTransformerBlock on the 320-channel level as ONE launch (xf_fused.hip: LayerNorm -> to_q -> attention over the L
+    context rows -> to_out + bias + residual; the accumulator blocks of each product are the B operand of the next) against torch; repeated
+    launches bit-equal (counted waits of the four-slot weight ring)."""
+    lib = _lib.load()
+    C, H = 320, 5
+    x = _rand((n * T, C), 400, 1.5)
+    gamma, beta = 1.0 + _rand((C,), 401, 0.2), _rand((C,), 402, 0.2)
+    wq, wk, wv = (_rand((C, C), 403 + i, 1 / math.sqrt(C)) for i in range(3))
+    wo, bo = _rand((C, C), 406, 1 / math.sqrt(C)), _rand((C,), 407, 0.2)
+    ctx = _rand((n, L, 1024), 408)
+    wkc, wvc = _rand((C, 1024), 409, 1 / 32.0), _rand((C, 1024), 410, 1 / 32.0)
+    k, v = F.linear(ctx, wkc).half().float(), F.linear(ctx, wvc).half().float()          # what the cached kv projection holds (fp16)
+    xn = F.layer_norm(x, (C,), gamma.half().float(), beta.half().float(), 1e-5).half().float()
+    q = F.linear(xn, wq).half().float().view(n, T, H, 64).transpose(1, 2)
+    o = F.scaled_dot_product_attention(q, k.view(n, L, H, 64).transpose(1, 2), v.view(n, L, H, 64).transpose(1, 2))
+    o = o.transpose(1, 2).reshape(n * T, C).half().float()
+    ref = x + F.linear(o, wo, bo)
+    dev = U.dev()
+    d = lambda t: t.half().contiguous().to(dev)
+    X, KV = d(x), d(torch.cat([k, v], -1))
+    G, B, WQ, WO, BO = d(gamma), d(beta), d(wq), d(wo), d(bo)
+    out = torch.empty_like(X)
+
+    def run():
+        rc = lib.ladi_op_xattn_block(ptr(X), ptr(G), ptr(B), 1e-5, ptr(WQ), ptr(KV), L, ptr(WO), ptr(BO), n, T, ptr(out), stream_ptr())
+        assert rc == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        return out.clone()
+    y = run()
+    assert U.rel_l2(y.float().cpu(), ref) < TOL, (n, T, L, U.rel_l2(y.float().cpu(), ref))
+    for _ in range(3):
+        assert torch.equal(run(), y)
+    # unsupported shapes are refused
+    assert lib.ladi_op_xattn_block(ptr(X), ptr(G), ptr(B), 1e-5, ptr(WQ), ptr(KV), 97, ptr(WO), ptr(BO), n, T, ptr(out), stream_ptr()) != 0
+    assert lib.ladi_op_xattn_block(ptr(X), ptr(G), ptr(B), 1e-5, ptr(WQ), ptr(KV), L, ptr(WO), ptr(BO), n, 96, ptr(out), stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("P,pipe", [(256, "1"), (3072, "1"), (128, "0"), (1024, "0")])
+def test_fused_feed_forward_block(P, pipe, monkeypatch):
+    """the feed-forward of a BasicTransformerBlock on the 320-channel level as ONE launch (LayerNorm -> GEGLU 320 -> 2 x 1280 -> 1280 -> 320 + bias
+    + residual; the hidden tensor never exists) against torch, both loop forms (LADI_FF_PIPE, read per launch)."""
+    monkeypatch.setenv("LADI_FF_PIPE", pipe)
+    lib = _lib.load()
+    C, HID = 320, 1280
+    x = _rand((P, C), 420, 1.5)
+    gamma, beta = 1.0 + _rand((C,), 421, 0.2), _rand((C,), 422, 0.2)
+    w1, b1 = _rand((2 * HID, C), 423, 1 / math.sqrt(C)), _rand((2 * HID,), 424, 0.1)
+    w2, bo = _rand((C, HID), 425, 1 / math.sqrt(HID)), _rand((C,), 426, 0.2)
+    xn = F.layer_norm(x, (C,), gamma.half().float(), beta.half().float(), 1e-5).half().float()
+    u, g = F.linear(xn, w1, b1).chunk(2, -1)
+    h = (u * F.gelu(g)).half().float()
+    ref = x + F.linear(h, w2, bo)
+    wi, bi = torch.zeros_like(w1), torch.zeros_like(b1)
+    for j in range(HID):
+        blk, i = divmod(j, 32)
+        wi[blk * 64 + i], wi[blk * 64 + 32 + i] = w1[j], w1[HID + j]
+        bi[blk * 64 + i], bi[blk * 64 + 32 + i] = b1[j], b1[HID + j]
+    dev = U.dev()
+    d = lambda t: t.half().contiguous().to(dev)
+    X, G, B, W1, B1, W2, BO = d(x), d(gamma), d(beta), d(wi), d(bi), d(w2), d(bo)
+    out = torch.empty_like(X)
+
+    def run():
+        rc = lib.ladi_op_ff_block(ptr(X), ptr(G), ptr(B), 1e-5, ptr(W1), ptr(B1), ptr(W2), ptr(BO), P, ptr(out), stream_ptr())
+        assert rc == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        return out.clone()
+    y = run()
+    assert U.rel_l2(y.float().cpu(), ref) < TOL, (P, pipe, U.rel_l2(y.float().cpu(), ref))
+    for _ in range(3):
+        assert torch.equal(run(), y)
+    assert lib.ladi_op_ff_block(ptr(X), ptr(G), ptr(B), 1e-5, ptr(W1), ptr(B1), ptr(W2), ptr(BO), 100, ptr(out), stream_ptr()) != 0
+
+
 def test_linear_x_stationary_rejects_unsupported():
     """explicitly requested on a shape / epilogue it does not cover -> error, never a silent wrong answer"""
     x = _rand((1, 320, 8, 8), 83)            # 64 pixels: not a whole 128-pixel panel
@@ -367,10 +443,14 @@ def test_gemm_f32_out():
 
 # --------------------------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("c0,c1,silu,hw", [(64, 0, 1, (12, 10)), (320, 0, 0, (12, 10)), (128, 64, 1, (12, 10)), (640, 320, 1, (12, 10)),
-                                           (320, 0, 1, (64, 48)), (1280, 1280, 1, (16, 12)), (128, 0, 1, (96, 64)), (256, 128, 0, (96, 64))])
-def test_group_norm(lib, c0, c1, silu, hw):
-    """partial rows -> per-channel scale / shift -> apply (+ SiLU, + add) over the virtual concat (c0 | c1), at UNet-like (64x48, 16x12)
-    and VAE-like (96x64, many partial rows) shapes"""
+                                           (320, 0, 1, (64, 48)), (1280, 1280, 1, (16, 12)), (128, 0, 1, (96, 64)), (256, 128, 0, (96, 64)),
+                                           (160, 0, 1, (16, 12)), (96, 32, 0, (8, 6)), (640, 320, 1, (32, 24)), (1920, 640, 1, (8, 6))])
+@pytest.mark.parametrize("onepass", ["1", "0"])
+def test_group_norm(lib, c0, c1, silu, hw, onepass, monkeypatch):
+    """partial rows -> (per-channel scale / shift ->) apply (+ SiLU, + add) over the virtual concat (c0 | c1), at UNet-like (64x48 ... 8x6)
+    and VAE-like (96x64, many partial rows) shapes.  onepass = 1: the one-launch form (every block finalises the groups of its own 64-channel
+    chunk -- groups that straddle chunk and source boundaries, a ragged last chunk) wherever it is eligible, 0: finalize + apply."""
+    monkeypatch.setenv("LADI_GN_ONEPASS", onepass)
     N, (h, w), G = 2, hw, 32
     a = _rand((N, c0, h, w), 31, 2.0) + 0.5
     b2 = _rand((N, c1, h, w), 32) if c1 else None
@@ -387,6 +467,10 @@ def test_group_norm(lib, c0, c1, silu, hw):
     assert rc == 0
     torch.cuda.synchronize()
     assert U.rel_l2(U.to_nchw(out), ref) < TOL
+    first = out.clone()
+    assert lib.ladi_op_group_norm(ptr(A), c0, ptr(B2), c1, N, h * w, G, ptr(g16), ptr(b16), 1e-5, silu, ptr(AD), ptr(out), ptr(stats), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, first)           # atomics-free, fixed summation order
 
 
 @pytest.mark.parametrize("C", [64, 320, 1280])
@@ -562,7 +646,7 @@ def test_conv3x3_relu_two_source(lib):
     x0, x1 = _rand((N, c0, h, w), 261), _rand((N, c1, h, w), 262)
     wt, b = _rand((cout, c0 + c1, 3, 3), 263, 1 / math.sqrt(9 * (c0 + c1))), _rand((cout,), 264, 0.3)
     ref = F.relu(F.conv2d(torch.cat([x0, x1], 1), wt, b, padding=1))
-    y = U.igemm(U.nhwc16(x0), U.pack_conv_weight_cat(wt, c0, c1), cout, x2=U.nhwc16(x1), bias=b, act="relu")
+    y = U.igemm(U.nhwc16(x0), U.pack_conv_weight(wt), cout, x2=U.nhwc16(x1), bias=b, act="relu")
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
     assert float(U.to_nchw(y).min()) == 0.0
 

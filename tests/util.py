@@ -32,11 +32,6 @@ def pack_conv_weight(w):
     return out.reshape(co, k * k * cp).contiguous().to(dev())
 
 
-def pack_conv_weight_cat(w, c0, c1):
-    """conv weight over a channel concat (c0 | c1), each padded separately? no: both are multiples of 64 in the model."""
-    return pack_conv_weight(w)
-
-
 def igemm(x, w_packed, cout, ksize=3, stride=1, pad=None, ups=0, x2=None, bias=None, rowadd=None, act="none", res0=None, res1=None,
           mask=None, out_f32=False, cfg=0, out_ld=None, ln=None, gn=None):
     """x, x2: NHWC fp16 gpu tensors [N,H,W,C]; returns NHWC output [N,Ho,Wo,ldo]"""
@@ -115,17 +110,34 @@ def cpu_quota_threads():
     return n
 
 
-def record_parity(key, value, name="parity_r04.json"):
-    """append a measured parity value to gpurun_out/<name> (copied to profiles/r03_parity.json after the run): every tolerance asserted in
-    the GPU tests has its measured value on record"""
-    import json
+PARITY_NAME = "parity_r05.json"
+
+
+def library_digest():
+    """sha256 over the sources / headers / flags libladi_native.so is built from (ladi_vton_amd/build.py: the stamp the loader checks)"""
+    from ladi_vton_amd import build
+    return build._digest()
+
+
+def parity_path():
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", root), "gpurun_out")
+    return os.path.join(os.environ.get("GRAFT_REPO_ROOT", root), "gpurun_out", PARITY_NAME)
+
+
+def record_parity(key, value, name=None):
+    """Measured parity values of the GPU suite -> gpurun_out/parity_r05.json (the only directory that comes back from the GPU box), stamped
+    with the library digest and the pytest session id: tests/conftest.py removes the file at the start of every GPU session, so the record
+    is ONE run of ONE binary, never a stitch.  `python tools/commit_parity.py` copies it to profiles/r05_parity.json after
+    checking the digest against the sources; tests/test_cpu.py checks that every key the documents cite is in the committed file."""
+    import json
+    import os
+    path = parity_path() if name is None else os.path.join(os.path.dirname(parity_path()), name)
     try:
-        os.makedirs(out, exist_ok=True)
-        path = os.path.join(out, name)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
         blob = json.load(open(path)) if os.path.exists(path) else {}
+        blob["_library_digest"] = library_digest()
+        blob.setdefault("_session", os.environ.get("LADI_PYTEST_SESSION", ""))
         blob[key] = value
         json.dump(blob, open(path, "w"), indent=1, sort_keys=True)
     except OSError:
