@@ -449,6 +449,18 @@ def main():
     dt = float(tt.item())
     assert out.shape[0] == global_B and out.dtype == torch.uint8
     images_per_s = global_B * a.steps / dt if a.steps else 0.0
+    # who took part in the collective (outside the timed region): the RCCL version and the number of DISTINCT ranks an all-gather of the rank ids
+    # returned on rank 0 -- so that a SCALE_rNN.json line can be checked for "RCCL saw N ranks" 
+    rccl = {"version": None, "ranks_seen": 1, "backend": None}
+    if dist.is_available() and dist.is_initialized():
+        ids = torch.empty((world,), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
+        rccl["ranks_seen"] = int(ids.unique().numel())
+        rccl["backend"] = dist.get_backend()
+        try:
+            rccl["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:       # noqa: BLE001  (reporting only)
+            rccl["version"] = "unavailable: %r" % (e,)
     # the same step WITH the reference's output tail (D2H + PIL + JPEG encode of every image, on rank 0's host cores),
     # timed separately so that `value` stays the device-resident number
     tail = None
@@ -559,7 +571,8 @@ def main():
                                    "checkpoint" % (cfg["name"], steps_inf, scheduler.upper(), evals, H, W, a.size),
                        "baseline_config_index": a.config, "batch_per_gpu": B, "global_batch": global_B, "producers_in_step": bool(producers),
                        "parallelism": "dp%d (contiguous row shards of the global batch + RCCL all-gather of uint8 images)" % world,
-                       "hipgraph": not a.no_graph, "unet_lanes": (lib.ladi_tryon_lanes(pipe._tryon) if pipe._tryon else None)},
+                       "hipgraph": not a.no_graph, "unet_lanes": (lib.ladi_tryon_lanes(pipe._tryon) if pipe._tryon else None),
+                       "rccl_ranks_seen": rccl["ranks_seen"], "rccl_version": rccl["version"], "collective_backend": rccl["backend"]},
             "stage_ms_rank0": stage_ms, "model_build_s": round(t_build, 1),
             "with_d2h_pil_images_per_s": tail["images_per_s"] if tail else None, "d2h_pil_tail": tail,
             "roofline": roofline, "cpu_baseline": cpu,

@@ -601,7 +601,10 @@ int ladi_op_group_norm(const void* src0, int C0, const void* src1, int C1, int n
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&buf), (f0 + f1 + fs) * sizeof(float)));
         int rc = ladi_launch_gn_partial((const h16*)src0, C0, C0, n, HW, buf, st);
         if (!rc && C1) rc = ladi_launch_gn_partial((const h16*)src1, C1, C1, n, HW, buf + f0, st);
-        if (!rc && ladi_gn_norm_eligible(C0, r0, C1, r1, groups)) {   // the form the runtime takes for the same operands (runtime_core.cpp group_norm)
+        if (!rc && ladi_gn_norm_direct(HW) && ladi_gn_norm_eligible(C0, 0, C1, 0, groups, HW)) {   // tiny samples: statistics from the data
+            rc = ladi_launch_gn_norm((const h16*)src0, C0, C0, nullptr, 0, (const h16*)src1, C1, C1, nullptr, 0, n, HW, groups, (const h16*)gamma,
+                                     (const h16*)beta, eps, silu, (const h16*)add, (h16*)out, st);
+        } else if (!rc && ladi_gn_norm_eligible(C0, r0, C1, r1, groups, HW)) {   // the form the runtime takes for the same operands (runtime_core.cpp group_norm)
             rc = ladi_launch_gn_norm((const h16*)src0, C0, C0, buf, r0, (const h16*)src1, C1, C1, buf + f0, r1, n, HW, groups, (const h16*)gamma,
                                      (const h16*)beta, eps, silu, (const h16*)add, (h16*)out, st);
         } else {

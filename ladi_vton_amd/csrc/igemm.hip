@@ -113,7 +113,7 @@ struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; in
 // tile configurations (0 = choose: measured per shape when autotuning is on, else the cost model below).
 // {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K,
 //  K step, offered to the tuner}
-constexpr int NCFG = 95;
+constexpr int NCFG = 96;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1, 0, false},
     {128, 256, 2, true, 0.80f, 4, 1, 1, 32, true},   // 1: <2,2,2,4> BK32 NST3
@@ -225,6 +225,11 @@ const CfgInfo kCfg[NCFG + 1] = {
     {1, 128, 3, true, 0.00f, 1, 93, 1, 0, true},     // 93: 32 pixels / wave, 1 channel slice
     {2, 128, 3, true, 0.00f, 1, 93, 1, 0, true},     // 94: 32 pixels / wave, 2 channel slices
     {5, 128, 3, true, 0.00f, 1, 93, 1, 0, true},     // 95: 32 pixels / wave, 5 channel slices
+    // 96 (round 5): halo 320x192 on FOUR waves, one per SIMD (160 x 96 per wave): the twelve-wave tile's fill of the 64x48 level with the
+    // LDS reads per MFMA of the one-wave-per-SIMD ring tiles
+    // measured (profiles/r05_halo_one_wave.txt): 107 us on the 320 -> 320 convolution where the twelve-wave form takes 92 -- at one wave per SIMD
+    // nothing covers the exposed halo-tile load of each channel chunk and the wave's own ds_read latency; kept selectable, not offered to the tuner
+    {320, 192, 1, false, 0.00f, 3, 96, 1, 64, false},  // 96: halo 320x192, 4 waves, one per SIMD
 };
 inline bool is_xs(int base) { return base == 23 || base == 93; }
 inline int xs_nst(int base) { return base == 93 ? 2 : 3; }
@@ -257,7 +262,7 @@ bool sk_two_pass_forced() {
     if (g_sk_two_pass < 0) g_sk_two_pass = getenv("LADI_SPLITK_TWO_PASS") != nullptr ? 1 : 0;
     return g_sk_two_pass == 1;
 }
-inline bool is_halo(int base) { return (base >= 74 && base <= 78) || base == 84 || base == 85 || base == 88 || base == 89 || base == 92; }
+inline bool is_halo(int base) { return (base >= 74 && base <= 78) || base == 84 || base == 85 || base == 88 || base == 89 || base == 92 || base == 96; }
 
 // rocprofv3's name of the kernel a configuration launches (bench.py groups its per-launch timings by symbol)
 std::string cfg_symbol(int c) {
@@ -281,6 +286,7 @@ std::string cfg_symbol(int c) {
         case 88: return "igemm_halo_kernel<2, 2, 1, 3, 2, 24>";
         case 89: return "igemm_halo_kernel<2, 3, 1, 3, 2, 24>";
         case 92: return "igemm_halo_kernel<5, 1, 1, 2, 6, 48>";
+        case 96: return "igemm_halo_kernel<5, 3, 1, 2, 2, 48, 1>";
         case 62: return "igemm_lc_kernel<2, 2, 2, 2, 2, 4>";
         case 63: return "igemm_lc_kernel<2, 2, 2, 2, 2, 5>";
         case 64: return "igemm_lc_kernel<2, 2, 4, 2, 2, 3>";
@@ -320,6 +326,7 @@ int launch_base(int cfg, const IGemmArgs& a, int batch, hipStream_t st) {
         case 88: return ladi_launch_igemm_halo(a, 2, 2, 11, batch, st);
         case 89: return ladi_launch_igemm_halo(a, 2, 3, 11, batch, st);
         case 92: return ladi_launch_igemm_halo(a, 5, 1, 12, batch, st);
+        case 96: return ladi_launch_igemm_halo(a, 5, 3, 13, batch, st);
         case 62: return ladi_launch_igemm_lc(a, 2, 2, 4, batch, st);
         case 63: return ladi_launch_igemm_lc(a, 2, 2, 5, batch, st);
         case 64: return ladi_launch_igemm_lc(a, 4, 2, 3, batch, st);

@@ -23,6 +23,13 @@
 namespace {
 
 constexpr int HALO_WMAX = 48;
+// Ablation switches for tools/r05/halo_ablate.hip (compiled with -DLADI_HALO_ABL=<mask>; the library never defines it, so every
+// `if constexpr` below folds to the full kernel): 1 = no weight DMA in the loop, 2 = no halo-tile DMA in the loop, 4 = no fragment ds_reads
+// (MFMAs on loop-invariant registers), 8 = no MFMAs (fragments kept alive), 16 = no per-step wait + barrier
+#ifndef LADI_HALO_ABL
+#define LADI_HALO_ABL 0
+#endif
+constexpr int ABL = LADI_HALO_ABL;
 
 // halo-tile passes issued at tap `tt` of a chunk that has a successor (the LX passes of the next chunk's tile are spread over taps 0..7)
 template <int LX>
@@ -44,8 +51,11 @@ constexpr int nx_sum(int t, int D, bool pf) {
 // WMAX: widest image row the halo buffer is sized for (48: every level of the UNet at 512x384; 24: the 32x24 level and below, whose smaller
 // buffer leaves room for a third weight slot at two workgroups per CU).  WPN = 6: twelve waves (2 x 6), three per SIMD -- the 320x192 tile
 // that covers the 64x48 level (49 152 pixels x 320 channels at batch 8) with exactly 256 workgroups.
-template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48>
-__global__ __launch_bounds__(128 * WPN, (WPN == 6 ? 3 : 2)) void igemm_halo_kernel(const IGemmArgs a) {
+// ONE = 1 (round 5): ONE workgroup of four waves per CU, one wave per SIMD with the whole 512-register file -- 320x192 as 2 x 2 waves of
+// 160 x 96 (240 accumulator registers, fragments double-buffered on top): per MFMA the wave reads 8 / 15 KB of fragments where the twelve-wave
+// form of the same tile reads 6 / 5 KB, and issues 20 DMA pieces per 60 MFMAs.
+template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48, int ONE = 0>
+__global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void igemm_halo_kernel(const IGemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only (see igemm_kernel.h)
     constexpr int WQ = 2, WP = WPN, BK = 64, NT = 128 * WPN;    // 8 waves (2 x 4), or 4 waves (2 x 2) with two workgroups per CU
     constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
@@ -196,14 +206,16 @@ __global__ __launch_bounds__(128 * WPN, (WPN == 6 ? 3 : 2)) void igemm_halo_kern
                 // (single halo buffer: the tile of this chunk was issued BEHIND the weight tiles at the end of the previous chunk, so the first
                 // tap drains everything)
                 const bool steady = (s - D >= s_begin) && (s + D - 1 < s_end) && !(NXB == 1 && t == 0);
-                if (steady && prefetch_x) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPF) : "memory");
-                else if (steady) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NNOPF) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                if (s + D < s_end) issue_w(s + D);
+                if constexpr (!(ABL & 16)) {
+                    if (steady && prefetch_x) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPF) : "memory");
+                    else if (steady) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NNOPF) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                if constexpr (!(ABL & 1)) { if (s + D < s_end) issue_w(s + D); }
                 if constexpr (NXB == 2 && t < 8) {
                     // a split-K slice may enter the chunk at tap t > 0: its first step also issues the passes of the taps it skipped
                     // (those steps are not "steady": they wait with vmcnt(0))
-                    if (prefetch_x) issue_x(c + 1, s == s_begin ? 0 : (LX * t) / 8, (LX * (t + 1)) / 8);
+                    if constexpr (!(ABL & 2)) { if (prefetch_x) issue_x(c + 1, s == s_begin ? 0 : (LX * t) / 8, (LX * (t + 1)) / 8); }
                 }
                 const h16* sW = smem + (s % NSTW) * WSLOT;
                 const int tshift = (t / 3 - 1) * Ws + (t % 3 - 1);
@@ -218,11 +230,18 @@ __global__ __launch_bounds__(128 * WPN, (WPN == 6 ? 3 : 2)) void igemm_halo_kern
                 }
                 // fragments double-buffered in registers when the accumulators leave room (the 320x256 tile holds 160 accumulator registers:
                 // single buffer there, its partner wave on the SIMD covers the LDS latency)
-                constexpr int DB = (TQ * TP * 16 + 2 * (TQ + TP) * 4 <= 200) ? 1 : 0;
+                constexpr int DB = (TQ * TP * 16 + 2 * (TQ + TP) * 4 <= (ONE ? 400 : 200)) ? 1 : 0;
                 h16x8 af[1 + DB][TQ], bf[1 + DB][TP];
                 auto load_frags = [&](auto Kc) {
                     constexpr int kk = decltype(Kc)::value;
                     const int chunk = kk * 2 + hh;
+                    if constexpr (ABL & 4) {                   // ablation: no LDS reads, the MFMAs run on opaque register contents
+#pragma unroll
+                        for (int i = 0; i < TQ; ++i) asm volatile("" : "=v"(af[kk & DB][i]));
+#pragma unroll
+                        for (int j = 0; j < TP; ++j) asm volatile("" : "=v"(bf[kk & DB][j]));
+                        return;
+                    }
 #pragma unroll
                     for (int i = 0; i < TQ; ++i) af[kk & DB][i] = *reinterpret_cast<const h16x8*>(sW + swz<BK>((wq * TQ + i) * 32 + l31, chunk));
 #pragma unroll
@@ -237,14 +256,18 @@ __global__ __launch_bounds__(128 * WPN, (WPN == 6 ? 3 : 2)) void igemm_halo_kern
                     for (int i = 0; i < TQ; ++i)
 #pragma unroll
                         for (int j = 0; j < TP; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & DB][i], bf[kk & DB][j], acc[i][j], 0, 0, 0);
+                        {
+                            const h16x8 fa = af[kk & DB][i], fb = bf[kk & DB][j];
+                            if constexpr (ABL & 8) asm volatile("" ::"v"(fa), "v"(fb));
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[i][j], 0, 0, 0);
+                        }
                 });
             }
         });
         if constexpr (NXB == 1) {
             if (c < c_last) {        // single halo buffer: every wave must be done with it before the next chunk's tile overwrites it
-                asm volatile("s_barrier" ::: "memory");
-                issue_x(c + 1, 0, LX);
+                if constexpr (!(ABL & 16)) asm volatile("s_barrier" ::: "memory");
+                if constexpr (!(ABL & 2)) issue_x(c + 1, 0, LX);
             }
         }
     }
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(128 * WPN, (WPN == 6 ? 3 : 2)) void igemm_halo_kern
 #endif
 }
 
-template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48>
+template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48, int ONE = 0>
 int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
     constexpr int BQ = 64 * TQ, BP = 32 * WPN * TP, RPP = 16 * WPN;
     constexpr int RQ = (BQ + RPP - 1) / RPP, XROWS = (BP + 2 * WMAX + 2 + RPP - 1) / RPP * RPP;
@@ -271,7 +294,7 @@ int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
     }
     if ((size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 >= 0x7FFFFFFFull) return -16;   // 32-bit byte offsets from the tensor base
     static bool attr_set = false;
-    auto kfn = igemm_halo_kernel<TQ, TP, NXB, NSTW, WPN, WMAX>;
+    auto kfn = igemm_halo_kernel<TQ, TP, NXB, NSTW, WPN, WMAX, ONE>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return -10;
         attr_set = true;
@@ -288,6 +311,7 @@ int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
 
 }  // namespace
 
+#ifndef LADI_HALO_TOOL   // tools/r05/halo_ablate.hip instantiates the one form it measures itself
 bool ladi_igemm_halo_eligible(const IGemmArgs& a, int batch) {
     return a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Ws <= HALO_WMAX && a.Ho == a.Hs && a.Wo == a.Ws && !(a.C0 % 64) && !(a.C1 % 64) &&
            batch == 1 && (size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 < 0x7FFFFFFFull;
@@ -308,5 +332,8 @@ int ladi_launch_igemm_halo(const IGemmArgs& a, int tq, int tp, int nxb, int batc
     if (tq == 2 && tp == 2 && nxb == 11) return launch_halo<2, 2, 1, 3, 2, 24>(a, batch, st);   // 128x128, 4 waves x 2 per CU, rows <= 24 pixels: 3 weight slots (72 KB)
     if (tq == 2 && tp == 3 && nxb == 11) return launch_halo<2, 3, 1, 3, 2, 24>(a, batch, st);   // 128x192, same
     if (tq == 5 && tp == 1 && nxb == 12) return launch_halo<5, 1, 1, 2, 6>(a, batch, st);       // 320x192, 12 waves (3 per SIMD), 144 KB
+    // round 5
+    if (tq == 5 && tp == 3 && nxb == 13) return launch_halo<5, 3, 1, 2, 2, 48, 1>(a, batch, st);   // 320x192, 4 waves, ONE per SIMD (240 accumulators), 120 KB
     return -7;
 }
+#endif  // LADI_HALO_TOOL

@@ -76,7 +76,10 @@ int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int 
                          const float* scale_shift, int silu, const h16* add, h16* out, hipStream_t st);
 // one-pass form (round 5): every block finalises the groups of its own 64-channel chunk from the partial rows (few rows per sample only:
 // ladi_gn_norm_eligible) and applies -- no gn_finalize launch, no scale / shift table
-bool ladi_gn_norm_eligible(int C0, int rps0, int C1, int rps1, int groups);
+// (rps = 0 with a null part pointer: that source has no partial rows and the kernel sums the data itself -- samples of <= 64 pixels only,
+// ladi_gn_norm_direct)
+bool ladi_gn_norm_direct(int HW);
+bool ladi_gn_norm_eligible(int C0, int rps0, int C1, int rps1, int groups, int HW);
 int ladi_launch_gn_norm(const h16* src0, int C0, int ld0, const float* part0, int rps0, const h16* src1, int C1, int ld1, const float* part1,
                         int rps1, int n, int HW, int groups, const h16* gamma, const h16* beta, float eps, int silu, const h16* add, h16* out,
                         hipStream_t st, int* bad = nullptr);

@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ s
 // gn_finalize + gn_apply: statistics fp32, y = fp16(act(x * scale + shift) (+ add)).
 constexpr int GNX_CH = 64;          // channels per block
 constexpr int GNX_MAX_GS = 96;      // largest group size handled (channels per group); stat channels <= 64 + 2 * 96 - 2 <= 256
-constexpr int GNX_MAX_RPS = 32;     // more partial rows per sample than this: the three-stage form (VAE-sized tensors)
+constexpr int GNX_DIRECT_HW = 64;   // samples of at most this many pixels: a source WITHOUT partial rows (rps = 0) has its statistics taken from the data
+constexpr int GNX_MAX_RPS = 96;     // more partial rows per sample than this: the three-stage form (VAE-sized tensors).  96 = the 64x48 level behind
+                                    // the 12-wave 320x192 halo tile, whose epilogue writes one row per 32 pixels (64 KB of L2-resident rows per block)
 __global__ __launch_bounds__(256) void gn_norm_kernel(const h16* __restrict__ src0, int C0, int ld0, const float* __restrict__ part0, int rps0,
                                                       const h16* __restrict__ src1, int C1, int ld1, const float* __restrict__ part1, int rps1,
                                                       int HW, int gs, const h16* __restrict__ gamma, const h16* __restrict__ beta, float eps,
@@ -207,8 +209,16 @@ __global__ __launch_bounds__(256) void gn_norm_kernel(const h16* __restrict__ sr
             const int c = cb + cl;
             const float* p; int C, rps, clc;
             if (c < C0) { p = part0; C = C0; rps = rps0; clc = c; } else { p = part1; C = C1; rps = rps1; clc = c - C0; }
-            const float2* row = reinterpret_cast<const float2*>(p) + (size_t)n * rps * C + clc;
-            for (int r = rl; r < rps; r += RL) { const float2 v = row[(size_t)r * C]; s += v.x; q += v.y; }
+            if (p) {
+                const float2* row = reinterpret_cast<const float2*>(p) + (size_t)n * rps * C + clc;
+                for (int r = rl; r < rps; r += RL) { const float2 v = row[(size_t)r * C]; s += v.x; q += v.y; }
+            } else {
+                // no partial rows for this source (the producer could not write them: 48-pixel samples are not whole 32-pixel row blocks) and
+                // the sample is tiny: the statistics come straight from the data -- no gn_partial launch (the 8x6 level of the UNet)
+                const h16* sp = (c < C0) ? src0 + clc : src1 + clc;
+                const int ldc = (c < C0) ? ld0 : ld1;
+                for (int r = rl; r < HW; r += RL) { const float x = (float)sp[((size_t)n * HW + r) * ldc]; s += x; q += x * x; }
+            }
             rsum[rl * ncs + cl] = s; rsq[rl * ncs + cl] = q;
         }
         __syncthreads();
@@ -431,20 +441,30 @@ int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int 
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 
-bool ladi_gn_norm_eligible(int C0, int rps0, int C1, int rps1, int groups) {
+bool ladi_gn_norm_direct(int HW) {
+    const char* e = getenv("LADI_GN_DIRECT");        // =0: always gn_partial (A/B)
+    return HW <= GNX_DIRECT_HW && !(e && e[0] == '0');
+}
+
+// rps = 0 for a source means "no partial rows: take the statistics from the data" (only for samples of <= GNX_DIRECT_HW pixels)
+bool ladi_gn_norm_eligible(int C0, int rps0, int C1, int rps1, int groups, int HW) {
     const char* e = getenv("LADI_GN_ONEPASS");       // read per call (host side, at graph-capture time): one process can A/B both forms
     const bool on = !(e && e[0] == '0');
     const int Ct = C0 + C1;
     if (!on || groups <= 0 || (Ct % groups)) return false;
     const int gs = Ct / groups;
-    return gs <= GNX_MAX_GS && rps0 >= 1 && rps0 <= GNX_MAX_RPS && (C1 == 0 || (rps1 >= 1 && rps1 <= GNX_MAX_RPS)) && groups * gs == Ct;
+    const char* me = getenv("LADI_GN_MAX_RPS");      // sweeps
+    const int max_rps = me ? atoi(me) : GNX_MAX_RPS;
+    const int lo = ladi_gn_norm_direct(HW) ? 0 : 1;
+    return gs <= GNX_MAX_GS && rps0 >= lo && rps0 <= max_rps && (C1 == 0 || (rps1 >= lo && rps1 <= max_rps)) && groups * gs == Ct;
 }
 
 int ladi_launch_gn_norm(const h16* src0, int C0, int ld0, const float* part0, int rps0, const h16* src1, int C1, int ld1, const float* part1,
                         int rps1, int n, int HW, int groups, const h16* gamma, const h16* beta, float eps, int silu, const h16* add, h16* out,
                         hipStream_t st, int* bad) {
     const int Ct = C0 + C1;
-    if ((C0 & 7) || (C1 & 7) || (ld0 & 7) || (C1 && (ld1 & 7)) || !ladi_gn_norm_eligible(C0, rps0, C1, rps1, groups)) return -1;
+    if ((C0 & 7) || (C1 & 7) || (ld0 & 7) || (C1 && (ld1 & 7)) || !ladi_gn_norm_eligible(C0, rps0, C1, rps1, groups, HW)) return -1;
+    if ((rps0 == 0 && part0) || (rps0 > 0 && !part0) || (C1 && ((rps1 == 0 && part1) || (rps1 > 0 && !part1)))) return -1;
     const int chunks = (Ct + GNX_CH - 1) / GNX_CH;
     // pixels per block: 128-byte row pieces x ppb rows; halve until the grid has ~3 blocks per CU (LADI_GN_PPB pins it: sweeps)
     const char* pe = getenv("LADI_GN_PPB");

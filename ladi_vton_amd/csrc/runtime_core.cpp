@@ -247,7 +247,7 @@ Act conv2d(Ctx& c, const DConv& cv, const Act& x, const Act* x2, const ConvOpt& 
 // GroupNorm over the virtual concat (x | x2): partial statistics come from the producers' epilogues when available
 namespace {
 struct GnParts { const float* part[2] = {nullptr, nullptr}; int rps[2] = {0, 0}; };
-GnParts gn_parts(Ctx& c, const Act& x, const Act* x2) {
+GnParts gn_parts(Ctx& c, const Act& x, const Act* x2, bool direct_ok) {
     const int HW = x.h * x.w;
     const Act* srcs[2] = {&x, x2};
     GnParts g;
@@ -260,6 +260,8 @@ GnParts gn_parts(Ctx& c, const Act& x, const Act* x2) {
         if (s->st_part && s->st_px > 0) {
             g.part[i] = s->st_part;
             g.rps[i] = HW / s->st_px;
+        } else if (direct_ok && ladi_gn_norm_direct(HW)) {
+            g.part[i] = nullptr; g.rps[i] = 0;      // tiny samples: the one-pass kernel takes the statistics from the data (no gn_partial launch)
         } else {
             if (!c.dry()) c.check(ladi_launch_gn_partial(s->p, s->c, s->ld, s->n, HW, p, c.st), "gn_partial");
             g.part[i] = p; g.rps[i] = rows;
@@ -274,7 +276,7 @@ float* gn_scale_shift(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int 
     if (C0 + C1 != nm.c) throw std::runtime_error("group_norm: channel mismatch");
     const int HW = x.h * x.w;
     float* ss = c.alloc_f32((size_t)x.n * (C0 + C1) * 2);
-    const GnParts g = gn_parts(c, x, x2);
+    const GnParts g = gn_parts(c, x, x2, false);
     if (!c.dry())
         c.check(ladi_launch_gn_finalize(g.part[0], C0, g.rps[0], g.part[1], C1, g.rps[1], x.n, HW, groups, nm.g, nm.b, eps, ss, c.st, c.bad), "gn_finalize");
     return ss;
@@ -287,9 +289,12 @@ Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups,
     Act out = c.new_act(x.n, x.h, x.w, C0 + C1);
     // (the scale / shift table is reserved whichever form runs: the arena plan does not depend on LADI_GN_ONEPASS)
     float* ss = c.alloc_f32((size_t)x.n * (C0 + C1) * 2);
-    const GnParts g = gn_parts(c, x, x2);
+    // (direct statistics only when the one-pass form will take the launch: group size and the other source's rows decide that)
+    const int gs = (C0 + C1) / groups;
+    const bool onepass_shape = ladi_gn_norm_eligible(C0, 1, C1, C1 ? 1 : 0, groups, HW) && gs * groups == C0 + C1;
+    GnParts g = gn_parts(c, x, x2, onepass_shape);
     if (c.dry()) return out;
-    if (ladi_gn_norm_eligible(C0, g.rps[0], C1, g.rps[1], groups)) {
+    if (ladi_gn_norm_eligible(C0, g.rps[0], C1, g.rps[1], groups, HW)) {
         // few partial rows per sample (every UNet level): each block finalises its own 64-channel chunk -- one launch instead of two
         c.check(ladi_launch_gn_norm(x.p, C0, x.ld, g.part[0], g.rps[0], x2 ? x2->p : nullptr, C1, x2 ? x2->ld : 0, g.part[1], g.rps[1], x.n, HW, groups,
                                     nm.g, nm.b, eps, silu, add ? add->p : nullptr, out.p, c.st, c.bad), "gn_norm");

@@ -299,7 +299,7 @@ def test_igemm8_is_race_free_and_deterministic(cfg):
     assert U.rel_l2(U.to_nchw(first), F.conv2d(x, wt, b, padding=1)) < TOL
 
 
-@pytest.mark.parametrize("cfg", [7, 9, 32, 39, 40, 45, 54, 56, 62, 64, 65, 68, 74, 76, 77, 84, 85])
+@pytest.mark.parametrize("cfg", [7, 9, 32, 39, 40, 45, 54, 56, 62, 64, 65, 68, 74, 76, 77, 84, 85, 92, 96])
 def test_fused_output_statistics(cfg):
     """per-channel partial statistics of the output (sum, sum of squares of the fp16-rounded values) written by the epilogue for the
     consuming GroupNorm: rows of [Q][2] per (TP*32)-pixel block -- 96-pixel blocks for the 320x192 / 256x192 tiles.  Summed over all rows
@@ -330,7 +330,7 @@ def test_fused_output_statistics(cfg):
 HALO_W24 = [88, 89, 90, 91]     # halo buffer sized for rows of <= 24 pixels (third weight slot at two workgroups per CU)
 
 
-@pytest.mark.parametrize("cfg", HALO + [79, 80, 86] + HALO_W24 + [92])
+@pytest.mark.parametrize("cfg", HALO + [79, 80, 86] + HALO_W24 + [92, 96])
 def test_conv3x3_halo_resident(cfg):
     """the halo-resident 3x3 convolution: the nine taps are applied when the B fragments are read from ONE staged pixel range, so what
     must be right is the tap shift / validity logic at image edges (left / right wrap-around, top / bottom rows, sample boundaries), the
@@ -459,7 +459,8 @@ def test_group_norm(lib, c0, c1, silu, hw, onepass, monkeypatch):
     xcat = torch.cat([a, b2], 1) if c1 else a
     ref = F.group_norm(xcat, G, gam, bet, 1e-5)
     ref = (F.silu(ref) if silu else ref) + add
-    A, B2, AD = U.nhwc16(a), (U.nhwc16(b2) if c1 else None), U.nhwc16(add)
+    exact = lambda t: t.permute(0, 2, 3, 1).half().contiguous().to(U.dev())       # NHWC with EXACTLY the tensor's channels (ld = C)
+    A, B2, AD = exact(a), (exact(b2) if c1 else None), exact(add)
     out = torch.empty((N, h, w, c0 + c1), dtype=torch.float16, device=U.dev())
     stats = torch.empty((N * G * 2,), dtype=torch.float32, device=U.dev())
     g16, b16 = gam.half().to(U.dev()), bet.half().to(U.dev())
