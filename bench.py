@@ -181,7 +181,7 @@ def traffic_measured(symbol, extra_args):
             "launches": vals["FETCH_SIZE"][1], "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled)"}, None
 
 
-PROFILE_ROUND = "r04"      # the committed rocprofv3 summaries this line may cite (profiles/<round>_*), digest-checked
+PROFILE_ROUND = "r05"      # the committed rocprofv3 summaries this line may cite (profiles/<round>_*), digest-checked
 
 
 def _pmc_file(prefix, tag):
@@ -217,7 +217,7 @@ def _stats_file(prefix):
     return out
 
 
-HBM_KERNELS = ("gn_apply_kernel", "gn_finalize_kernel", "gn_partial_kernel", "splitk_reduce_kernel", "layernorm_kernel", "sched_step_kernel",
+HBM_KERNELS = ("gn_norm_kernel", "gn_apply_kernel", "gn_finalize_kernel", "gn_partial_kernel", "splitk_reduce_kernel", "layernorm_kernel", "sched_step_kernel",
                "image_post_kernel", "assemble_static_kernel")
 
 

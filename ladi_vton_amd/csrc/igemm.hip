@@ -113,7 +113,7 @@ struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; in
 // tile configurations (0 = choose: measured per shape when autotuning is on, else the cost model below).
 // {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K,
 //  K step, offered to the tuner}
-constexpr int NCFG = 96;
+constexpr int NCFG = 103;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1, 0, false},
     {128, 256, 2, true, 0.80f, 4, 1, 1, 32, true},   // 1: <2,2,2,4> BK32 NST3
@@ -230,6 +230,18 @@ const CfgInfo kCfg[NCFG + 1] = {
     // measured (profiles/r05_halo_one_wave.txt): 107 us on the 320 -> 320 convolution where the twelve-wave form takes 92 -- at one wave per SIMD
     // nothing covers the exposed halo-tile load of each channel chunk and the wave's own ds_read latency; kept selectable, not offered to the tuner
     {320, 192, 1, false, 0.00f, 3, 96, 1, 64, false},  // 96: halo 320x192, 4 waves, one per SIMD
+    // 97..99 (round 5): halo 128x256 on four waves of 64 x 128, two workgroups per CU, rows <= 24 pixels -- what the ablation of cfg 88 asks for
+    // (profiles/r05_halo_ablate.txt: its fragment reads cost twice what its DMA costs): 0.75 KB of LDS reads per MFMA instead of 1, half the
+    // weight DMA per MFMA; split-K keeps two workgroups per CU on the 32x24 / 16x12 levels
+    {128, 256, 2, false, 0.00f, 4, 97, 1, 64, true},  // 97: halo 128x256, 4 waves, W <= 24
+    {128, 256, 2, false, 0.00f, 4, 97, 2, 64, true},  // 98: cfg 97 + split-K 2
+    {128, 256, 2, false, 0.00f, 4, 97, 4, 64, true},  // 99: cfg 97 + split-K 4
+    // 100..103 (round 5): 2-D BLOCKED halo tiles (igemm_halo.hip G2D): stride-1 3x3 convolutions on images wider than 48 pixels -- the VAE /
+    // EMASC levels above 64x48 and the 128x96 latent grid of 1024x768 -- stage (TH + 2) x 34 pixels per TH x 32 block instead of nine shifted copies
+    {128, 256, 1, false, 0.00f, 2, 100, 1, 64, true},  // 100: halo2d 128x256 (8 rows x 32), 8 waves
+    {256, 256, 1, false, 0.00f, 2, 101, 1, 64, true},  // 101: halo2d 256x256, 8 waves
+    {320, 256, 1, false, 0.00f, 2, 102, 1, 64, true},  // 102: halo2d 320x256, 8 waves
+    {128, 128, 2, false, 0.00f, 2, 103, 1, 64, true},  // 103: halo2d 128x128 (4 rows x 32), 4 waves, two workgroups per CU
 };
 inline bool is_xs(int base) { return base == 23 || base == 93; }
 inline int xs_nst(int base) { return base == 93 ? 2 : 3; }
@@ -262,7 +274,9 @@ bool sk_two_pass_forced() {
     if (g_sk_two_pass < 0) g_sk_two_pass = getenv("LADI_SPLITK_TWO_PASS") != nullptr ? 1 : 0;
     return g_sk_two_pass == 1;
 }
-inline bool is_halo(int base) { return (base >= 74 && base <= 78) || base == 84 || base == 85 || base == 88 || base == 89 || base == 92 || base == 96; }
+inline bool is_halo(int base) { return (base >= 74 && base <= 78) || base == 84 || base == 85 || base == 88 || base == 89 || base == 92 || base == 96 || base == 97; }
+inline bool is_halo2d(int base) { return base >= 100 && base <= 103; }
+inline int halo2d_th(int base) { return base == 103 ? 4 : 8; }
 
 // rocprofv3's name of the kernel a configuration launches (bench.py groups its per-launch timings by symbol)
 std::string cfg_symbol(int c) {
@@ -287,6 +301,11 @@ std::string cfg_symbol(int c) {
         case 89: return "igemm_halo_kernel<2, 3, 1, 3, 2, 24>";
         case 92: return "igemm_halo_kernel<5, 1, 1, 2, 6, 48>";
         case 96: return "igemm_halo_kernel<5, 3, 1, 2, 2, 48, 1>";
+        case 97: return "igemm_halo_kernel<2, 4, 1, 2, 2, 24>";
+        case 100: return "igemm_halo_kernel<2, 2, 1, 3, 4, 48, 0, 1>";
+        case 101: return "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 1>";
+        case 102: return "igemm_halo_kernel<5, 2, 1, 2, 4, 48, 0, 1>";
+        case 103: return "igemm_halo_kernel<2, 2, 1, 2, 2, 48, 0, 1>";
         case 62: return "igemm_lc_kernel<2, 2, 2, 2, 2, 4>";
         case 63: return "igemm_lc_kernel<2, 2, 2, 2, 2, 5>";
         case 64: return "igemm_lc_kernel<2, 2, 4, 2, 2, 3>";
@@ -327,6 +346,11 @@ int launch_base(int cfg, const IGemmArgs& a, int batch, hipStream_t st) {
         case 89: return ladi_launch_igemm_halo(a, 2, 3, 11, batch, st);
         case 92: return ladi_launch_igemm_halo(a, 5, 1, 12, batch, st);
         case 96: return ladi_launch_igemm_halo(a, 5, 3, 13, batch, st);
+        case 97: return ladi_launch_igemm_halo(a, 2, 4, 11, batch, st);
+        case 100: return ladi_launch_igemm_halo(a, 2, 2, 20, batch, st);
+        case 101: return ladi_launch_igemm_halo(a, 4, 2, 20, batch, st);
+        case 102: return ladi_launch_igemm_halo(a, 5, 2, 20, batch, st);
+        case 103: return ladi_launch_igemm_halo(a, 2, 2, 21, batch, st);
         case 62: return ladi_launch_igemm_lc(a, 2, 2, 4, batch, st);
         case 63: return ladi_launch_igemm_lc(a, 2, 2, 5, batch, st);
         case 64: return ladi_launch_igemm_lc(a, 4, 2, 3, batch, st);
@@ -428,7 +452,8 @@ static bool cfg_admissible(const IGemmArgs& a, int batch, int c, bool strict) {
     if (a.gn_ss) return false;                                        // GroupNorm affine of the operand: X-stationary kernel only
     if (a.ln_gamma && !a.ln_scratch) return false;                    // no scratch: only the fused (X-stationary) form
     if (is_lc(ci.base) && (a.ups || batch != 1)) return false;        // loader / consumer kernel: no folded upsample, no batched launches
-    if (is_halo(ci.base) && (!ladi_igemm_halo_eligible(a, batch) || ((ci.base == 88 || ci.base == 89) && a.Ws > 24))) return false;   // halo-resident kernel: 3x3 stride-1 convolutions on narrow images
+    if (is_halo2d(ci.base) && !ladi_igemm_halo2d_eligible(a, batch, halo2d_th(ci.base))) return false;   // 2-D blocked halo: W % 32 == 0, whole blocks
+    if (is_halo(ci.base) && (!ladi_igemm_halo_eligible(a, batch) || ((ci.base == 88 || ci.base == 89 || ci.base == 97) && a.Ws > 24))) return false;   // halo-resident kernel: 3x3 stride-1 convolutions on narrow images
     if (geglu && !ci.geglu_ok) return false;
     if (ci.bk == 64 && ((a.C0 % 64) || (a.C1 % 64))) return false;
     if (ci.split > 1 && (batch != 1 || geglu || a.out_f32 || a.bias_per_pixel)) return false;

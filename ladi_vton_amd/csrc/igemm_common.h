@@ -25,7 +25,7 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 // ------------------------------------------------------------------------------------------------
 template <int WQ, int WP, int TQ, int TP>
 __device__ __forceinline__ void igemm_epilogue_generic(const IGemmArgs& a, f32x16 (&acc)[TQ][TP], h16* smem, const int q0, const int p0,
-                                                       const int pt, const int z, const int wave, const int lane) {
+                                                       const int pt, const int z, const int wave, const int lane, const int pstr = 32) {
     const int wq = wave / WP, wp = wave % WP;
     const int l31 = lane & 31, hh = lane >> 5;
     const float bmul = a.bias_mul != 0.f ? a.bias_mul : 1.f;
@@ -44,7 +44,7 @@ __device__ __forceinline__ void igemm_epilogue_generic(const IGemmArgs& a, f32x1
     int pj[TP]; bool prow[TP]; float pbj[TP];
     static_for<0, TP>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
-        pj[j] = p0 + (wp * TP + j) * 32 + l31;
+        pj[j] = p0 + (wp * TP + j) * pstr + l31;
         prow[j] = pj[j] < a.P;
         pbj[j] = (prow[j] && a.bias && a.bias_per_pixel) ? (float)a.bias[pj[j]] * bmul : 0.f;
     });
@@ -137,7 +137,7 @@ __device__ __forceinline__ void igemm_epilogue_generic(const IGemmArgs& a, f32x1
         });
         __builtin_amdgcn_wave_barrier();
         // (2) lane = (pixel row, 8-channel chunk): residuals, mask, statistics, 16-byte coalesced stores
-        const int pbase = p0 + (wp * TP + j) * 32;
+        const int pbase = p0 + (wp * TP + j) * pstr;
         for (int r = 0; r < 32; r += RPW) {
             const int prw = r + rb_row;
             const int p = pbase + prw;
@@ -225,7 +225,7 @@ __device__ __forceinline__ void igemm_epilogue_generic(const IGemmArgs& a, f32x1
 //     and stores overlap.
 template <int WQ, int WP, int TQ, int TP, bool GEGLU>
 __device__ __forceinline__ void igemm_epilogue_fast(const IGemmArgs& a, f32x16 (&acc)[TQ][TP], h16* smem, const int q0, const int p0,
-                                                    const int pt, const int z, const int wave, const int lane) {
+                                                    const int pt, const int z, const int wave, const int lane, const int pstr = 32) {
     static_assert(!GEGLU || (TQ % 2 == 0), "GEGLU pairs 32-row blocks (u | g)");
     constexpr int NW = WQ * WP, NT = 64 * NW, BQ = WQ * TQ * 32;
     constexpr int CWF = TQ * 32;                    // W rows of this wave
@@ -271,7 +271,7 @@ __device__ __forceinline__ void igemm_epilogue_fast(const IGemmArgs& a, f32x16 (
 
     static_for<0, TP>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
-        const int pbase = p0 + (wp * TP + j) * 32;
+        const int pbase = p0 + (wp * TP + j) * pstr;
         // (1) lane = pixel column: per-channel vector / activation, round to fp16, 8-byte LDS writes
         const int pcol = pbase + l31;
         const float pb = (a.bias && a.bias_per_pixel && pcol < a.P) ? (float)a.bias[pcol] * bmul : 0.f;
@@ -466,9 +466,11 @@ __device__ __forceinline__ bool igemm_splitk_combine(const IGemmArgs& a, f32x16 
     return true;
 }
 
+// pstr: pixel-index distance between consecutive 32-pixel sub-tiles of the workgroup tile -- 32 for tiles of consecutive pixels (every kernel
+// but the 2-D blocked halo form, whose sub-tiles are 32-pixel segments of consecutive IMAGE ROWS: pstr = image width, p0 = first pixel of the block)
 template <int WQ, int WP, int TQ, int TP>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& a, f32x16 (&acc)[TQ][TP], h16* smem, const int q0, const int p0,
-                                               const int pt, const int z_in, const int wave, const int lane) {
+                                               const int pt, const int z_in, const int wave, const int lane, const int pstr = 32) {
     int z = z_in;
     if (a.splitk > 1 && a.sk_cnt) {      // in-launch split-K: only the last-arriving slice of a tile runs the fused epilogue
         if (!igemm_splitk_combine<WQ, WP, TQ, TP>(a, acc, smem, q0, pt, z, wave, lane)) return;
@@ -482,11 +484,11 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& a, f32x16 (&acc)
                       !(((size_t)z * a.bs_out | (size_t)z * a.bs_res) & 7) && (!a.stats || !(reinterpret_cast<uintptr_t>(a.stats) & 15));
     if (fast) {
         if constexpr (TQ % 2 == 0) {
-            if (geglu) { igemm_epilogue_fast<WQ, WP, TQ, TP, true>(a, acc, smem, q0, p0, pt, z, wave, lane); return; }
+            if (geglu) { igemm_epilogue_fast<WQ, WP, TQ, TP, true>(a, acc, smem, q0, p0, pt, z, wave, lane, pstr); return; }
         }
-        if (!geglu) { igemm_epilogue_fast<WQ, WP, TQ, TP, false>(a, acc, smem, q0, p0, pt, z, wave, lane); return; }
+        if (!geglu) { igemm_epilogue_fast<WQ, WP, TQ, TP, false>(a, acc, smem, q0, p0, pt, z, wave, lane, pstr); return; }
     }
-    igemm_epilogue_generic<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane);
+    igemm_epilogue_generic<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane, pstr);
 }
 
 }  // namespace

@@ -54,14 +54,22 @@ constexpr int nx_sum(int t, int D, bool pf) {
 // ONE = 1 (round 5): ONE workgroup of four waves per CU, one wave per SIMD with the whole 512-register file -- 320x192 as 2 x 2 waves of
 // 160 x 96 (240 accumulator registers, fragments double-buffered on top): per MFMA the wave reads 8 / 15 KB of fragments where the twelve-wave
 // form of the same tile reads 6 / 5 KB, and issues 20 DMA pieces per 60 MFMAs.
-template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48, int ONE = 0>
+// G2D = 1 (round 5): 2-D BLOCKED halo tile for images whose rows are wider than WMAX pixels (every VAE / EMASC level above 64x48, the 128x96
+// latent grid of 1024x768).  The pixel tile is TH = BP / 32 image rows x 32 columns; the staged block is (TH + 2) x 34 pixels stored with a row
+// pitch of 34, so a tap is again a LINEAR shift of the row index -- (dy - 1) * 34 + (dx - 1) -- and, because the left / right neighbours are
+// real halo columns (zero-filled by the descriptor's bounds check outside the image), the consumer needs no validity masks at all.  Staged
+// rows per chunk: (TH + 2) * 34 for TH * 32 pixels (1.33x at TH = 8) where the ring kernels stage 9x.  Requires W % 32 == 0, H % TH == 0
+// (whole blocks), a single halo buffer (NXB = 1); the epilogue sees sub-tiles one image row apart (igemm_epilogue pstr = W).
+template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48, int ONE = 0, int G2D = 0>
 __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void igemm_halo_kernel(const IGemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only (see igemm_kernel.h)
     constexpr int WQ = 2, WP = WPN, BK = 64, NT = 128 * WPN;    // 8 waves (2 x 4), or 4 waves (2 x 2) with two workgroups per CU
     constexpr int BQ = WQ * TQ * 32, BP = WP * TP * 32;
     constexpr int RPP = NT / 8;                                  // 64 tile rows per DMA pass of the workgroup
     constexpr int RQ = (BQ + RPP - 1) / RPP;                     // weight passes per tap
-    constexpr int XROWS = (BP + 2 * WMAX + 2 + RPP - 1) / RPP * RPP;   // rows of one halo-tile buffer (whole passes)
+    constexpr int TH = BP / 32, HC = 34;                         // G2D: image rows per block, row pitch of the staged block (32 + 2 halo columns)
+    static_assert(!G2D || NXB == 1, "the 2-D blocked form keeps one halo buffer");
+    constexpr int XROWS = ((G2D ? (TH + 2) * HC : BP + 2 * WMAX + 2) + RPP - 1) / RPP * RPP;   // rows of one halo-tile buffer (whole passes)
     constexpr int LX = XROWS / RPP;                              // halo passes per channel chunk
     constexpr int WSLOT = RQ * RPP * BK;                         // halves per weight slot (padded to whole passes)
     constexpr int XBUF = XROWS * BK;                             // halves per halo buffer
@@ -91,7 +99,16 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
             if (qt >= nq) return;
         } else { qt = b % nq; pt = b / nq; }
     }
-    const int q0 = qt * BQ, p0 = pt * BP;
+    const int q0 = qt * BQ;
+    // G2D: block pt = (sample, block row, block column); p0 = pixel index of the block's first pixel, sub-tile r is image row y0 + r
+    int g_n = 0, g_y0 = 0, g_x0 = 0;
+    if constexpr (G2D) {
+        const int txn = a.Ws >> 5, tps = (a.Hs / TH) * txn;
+        g_n = pt / tps;
+        const int t = pt - g_n * tps, ty = t / txn;
+        g_y0 = ty * TH; g_x0 = (t - ty * txn) * 32;
+    }
+    const int p0 = G2D ? (g_n * a.Hs + g_y0) * a.Ws + g_x0 : pt * BP;
     const int z = blockIdx.z;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -122,9 +139,15 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
 #pragma unroll
     for (int i = 0; i < LX; ++i) {
         const int row = r0 + RPP * i;                            // halo-tile row = input pixel p0 - Ws - 1 + row
-        const long long pin = (long long)p0 - Ws - 1 + row;
+        long long pin = (long long)p0 - Ws - 1 + row;
         const int clog = c8 ^ ((row >> 1) & 7);
-        const bool ok = pin >= 0 && pin < a.P;
+        bool ok = pin >= 0 && pin < a.P;
+        if constexpr (G2D) {                                     // row = (block row rr, block column cc) of the (TH + 2) x 34 block
+            const int rr = row / HC, cc = row - rr * HC;
+            const int y = g_y0 - 1 + rr, x = g_x0 - 1 + cc;
+            ok = rr < TH + 2 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+            pin = ((long long)g_n * Hs + y) * Ws + x;
+        }
         xo0[i] = ok ? (unsigned)((pin * a.ld0 + clog * 8) * 2) : OOB;
         xo1[i] = ok ? (unsigned)((pin * a.ld1 + clog * 8) * 2) : OOB;
     }
@@ -133,9 +156,9 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int pl = (wp * TP + j) * 32 + l31, p = p0 + pl;
-        rb[j] = pl + Ws + 1;
-        unsigned m = 0;
-        if (p < a.P) {
+        rb[j] = G2D ? (wp * TP + j + 1) * HC + l31 + 1 : pl + Ws + 1;
+        unsigned m = G2D ? 0x1ffu : 0u;                          // G2D: whole blocks inside the image, out-of-image taps are zero-filled halo pixels
+        if (!G2D && p < a.P) {
             const int rem = p % HW, oy = rem / Ws, ox = rem - oy * Ws;
 #pragma unroll
             for (int t = 0; t < 9; ++t)
@@ -218,7 +241,7 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
                     if constexpr (!(ABL & 2)) { if (prefetch_x) issue_x(c + 1, s == s_begin ? 0 : (LX * t) / 8, (LX * (t + 1)) / 8); }
                 }
                 const h16* sW = smem + (s % NSTW) * WSLOT;
-                const int tshift = (t / 3 - 1) * Ws + (t % 3 - 1);
+                const int tshift = (t / 3 - 1) * (G2D ? HC : Ws) + (t % 3 - 1);
                 int xoff[TP];          // half offset of the lane's row in the halo tile (or the zero row), swizzle term separate
                 int xsw[TP];
 #pragma unroll
@@ -272,19 +295,20 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    igemm_epilogue<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane);
+    igemm_epilogue<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane, G2D ? Ws : 32);
 #endif
 }
 
-template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48, int ONE = 0>
+template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48, int ONE = 0, int G2D = 0>
 int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
     constexpr int BQ = 64 * TQ, BP = 32 * WPN * TP, RPP = 16 * WPN;
-    constexpr int RQ = (BQ + RPP - 1) / RPP, XROWS = (BP + 2 * WMAX + 2 + RPP - 1) / RPP * RPP;
+    constexpr int RQ = (BQ + RPP - 1) / RPP, XROWS = ((G2D ? (BP / 32 + 2) * 34 : BP + 2 * WMAX + 2) + RPP - 1) / RPP * RPP;
     constexpr int SMEM = (NSTW * RQ * RPP * 64 + NXB * XROWS * 64) * (int)sizeof(h16) + 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget of one CU");
     static_assert(SMEM >= igemm_epilogue_lds_bytes<2, WPN, TQ>(), "epilogue patches must fit");
-    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups || a.Ws > WMAX || a.Ho != a.Hs || a.Wo != a.Ws) return -16;
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups || (!G2D && a.Ws > WMAX) || a.Ho != a.Hs || a.Wo != a.Ws) return -16;
     if ((a.C0 % 64) || (a.C1 % 64) || (batch != 1 && a.splitk <= 1)) return -16;
+    if (G2D && ((a.Ws % 32) || (a.Hs % (BP / 32)) || batch != 1 || a.splitk > 1)) return -16;   // whole (BP / 32) x 32 blocks, no split-K
     if (NXB == 2 && a.splitk > 1) {
         // a K slice that ENTERS a chunk at its last tap would never prefetch the next chunk's halo tile (the passes ride on taps 0..7):
         // such a split is refused here rather than mis-computed (unreachable with the shipped split factors 2 and 4)
@@ -294,7 +318,7 @@ int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
     }
     if ((size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 >= 0x7FFFFFFFull) return -16;   // 32-bit byte offsets from the tensor base
     static bool attr_set = false;
-    auto kfn = igemm_halo_kernel<TQ, TP, NXB, NSTW, WPN, WMAX, ONE>;
+    auto kfn = igemm_halo_kernel<TQ, TP, NXB, NSTW, WPN, WMAX, ONE, G2D>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return -10;
         attr_set = true;
@@ -317,6 +341,12 @@ bool ladi_igemm_halo_eligible(const IGemmArgs& a, int batch) {
            batch == 1 && (size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 < 0x7FFFFFFFull;
 }
 
+// 2-D blocked form: rows of any width that is a multiple of 32, whole blocks of `th` image rows
+bool ladi_igemm_halo2d_eligible(const IGemmArgs& a, int batch, int th) {
+    return a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Ho == a.Hs && a.Wo == a.Ws && !(a.C0 % 64) && !(a.C1 % 64) && batch == 1 &&
+           !(a.Ws % 32) && th > 0 && !(a.Hs % th) && (size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 < 0x7FFFFFFFull;
+}
+
 // (tq, tp): wave tile in 32-blocks on the 2 x 4 wave grid -> workgroup tile (64 tq) x (128 tp); nxb: halo buffers (10: the 4-wave form,
 // 2 x 2 waves -> (64 tq) x (64 tp), one halo buffer)
 int ladi_launch_igemm_halo(const IGemmArgs& a, int tq, int tp, int nxb, int batch, hipStream_t st) {
@@ -334,6 +364,12 @@ int ladi_launch_igemm_halo(const IGemmArgs& a, int tq, int tp, int nxb, int batc
     if (tq == 5 && tp == 1 && nxb == 12) return launch_halo<5, 1, 1, 2, 6>(a, batch, st);       // 320x192, 12 waves (3 per SIMD), 144 KB
     // round 5
     if (tq == 5 && tp == 3 && nxb == 13) return launch_halo<5, 3, 1, 2, 2, 48, 1>(a, batch, st);   // 320x192, 4 waves, ONE per SIMD (240 accumulators), 120 KB
+    // round 5: 2-D blocked halo tiles (nxb 20 + ...): images wider than 48 pixels
+    if (tq == 2 && tp == 2 && nxb == 20) return launch_halo<2, 2, 1, 3, 4, 48, 0, 1>(a, batch, st);   // 128x256 (8 rows x 32), 8 waves, 96 KB
+    if (tq == 4 && tp == 2 && nxb == 20) return launch_halo<4, 2, 1, 3, 4, 48, 0, 1>(a, batch, st);   // 256x256, 8 waves, 144 KB
+    if (tq == 5 && tp == 2 && nxb == 20) return launch_halo<5, 2, 1, 2, 4, 48, 0, 1>(a, batch, st);   // 320x256, 8 waves, 128 KB
+    if (tq == 2 && tp == 2 && nxb == 21) return launch_halo<2, 2, 1, 2, 2, 48, 0, 1>(a, batch, st);   // 128x128 (4 rows x 32), 4 waves x 2 per CU, 60 KB
+    if (tq == 2 && tp == 4 && nxb == 11) return launch_halo<2, 4, 1, 2, 2, 24>(a, batch, st);      // 128x256, 4 waves (64 x 128 each: 0.75 KB of fragment reads per MFMA, half the weight DMA per MFMA of 128x128) x 2 per CU, rows <= 24 pixels (72 KB)
     return -7;
 }
 #endif  // LADI_HALO_TOOL

@@ -327,7 +327,7 @@ def test_fused_output_statistics(cfg):
     assert U.rel_l2(tot[:, 0], o.sum(0).cpu()) < 1e-4 and U.rel_l2(tot[:, 1], (o * o).sum(0).cpu()) < 1e-4
 
 
-HALO_W24 = [88, 89, 90, 91]     # halo buffer sized for rows of <= 24 pixels (third weight slot at two workgroups per CU)
+HALO_W24 = [88, 89, 90, 91, 97, 98, 99]     # halo buffer sized for rows of <= 24 pixels (third weight slot at two workgroups per CU)
 
 
 @pytest.mark.parametrize("cfg", HALO + [79, 80, 86] + HALO_W24 + [92, 96])
@@ -367,6 +367,67 @@ def test_conv3x3_halo_resident(cfg):
         xw = _rand((1, 64, 4, 32), 94)
         with pytest.raises(AssertionError):
             U.igemm(U.nhwc16(xw), U.pack_conv_weight(w3), 64, cfg=cfg)
+
+
+HALO2D = [100, 101, 102, 103]     # round 5: 2-D blocked halo tiles (th x 32 pixel blocks) for images wider than 48 pixels
+
+
+@pytest.mark.parametrize("cfg", HALO2D)
+def test_conv3x3_halo_2d_blocked(cfg):
+    """the 2-D blocked halo form (igemm_halo.hip G2D): blocks of th image rows x 32 columns staged with their one-pixel frame, taps as linear
+    shifts inside the (th + 2) x 34 block, sub-tiles written one IMAGE ROW apart.  What must be right: block -> (sample, row, column) mapping
+    over several samples, the zero frame at all four image edges and between samples, the two-source K loop over several channel chunks,
+    residual / mask / activation in the row-strided epilogue, the output statistics (rows per 64 pixels), bit-equal repeats; shapes that are
+    not whole blocks are refused."""
+    lib = _lib.load()
+    th = 4 if cfg == 103 else 8
+    for (N, c0, c1, cout, h, w_, act, seed) in ((2, 128, 0, 128, 16, 64, "none", 170), (1, 64, 64, 320, 8, 96, "silu", 174), (3, 256, 0, 256, 24, 32, "none", 178),
+                                               (2, 64, 0, 96, 2 * th, 160, "silu", 182)):
+        xa = _rand((N, c0, h, w_), seed)
+        xb = _rand((N, c1, h, w_), seed + 1) if c1 else None
+        wt, b = _rand((cout, c0 + c1, 3, 3), seed + 2, 1 / math.sqrt(9 * (c0 + c1))), _rand((cout,), seed + 3, 0.1)
+        res = _rand((N, cout, h, w_), seed + 4)
+        mask = (torch.rand((N, 1, h, w_), generator=torch.Generator().manual_seed(seed + 5)) > 0.5).float()
+        xin = torch.cat([xa, xb], 1) if c1 else xa
+        ref = F.conv2d(xin, wt, b, padding=1)
+        ref = ((F.silu(ref) if act == "silu" else ref) + res) * (1.0 - mask)
+        M = mask.permute(0, 2, 3, 1).reshape(-1).half().contiguous().to(U.dev())
+        args = dict(bias=b, act=act, res0=U.nhwc16(res), mask=M, cfg=cfg)
+        if c1:
+            args["x2"] = U.nhwc16(xb)
+        Xa, Wp = U.nhwc16(xa), U.pack_conv_weight(wt)
+        y = U.igemm(Xa, Wp, cout, **args)
+        assert U.rel_l2(U.to_nchw(y)[:, :cout], ref) < TOL, (cfg, N, c0, c1, cout, h, w_)
+        for _ in range(3):
+            assert torch.equal(U.igemm(Xa, Wp, cout, **args), y)
+    # output statistics through the row-strided epilogue: all rows of a sample sum to the per-channel totals of what was stored
+    N, cin, cout, h, w_ = 2, 128, 128, 16, 64
+    x, wt, b = _rand((N, cin, h, w_), 190), _rand((cout, cin, 3, 3), 191, 1 / math.sqrt(9 * cin)), _rand((cout,), 192, 0.1)
+    X, Wp, B16 = U.nhwc16(x), U.pack_conv_weight(wt), b.half().to(U.dev())
+    out = torch.zeros((N, h, w_, cout), dtype=torch.float16, device=U.dev())
+    rows = N * h * w_ // 32
+    stats = torch.zeros((rows, cout, 2), dtype=torch.float32, device=U.dev())
+    d = _lib.IGemmDesc()
+    d.src0, d.C0, d.ld0 = X.data_ptr(), cin, cin
+    d.Hs, d.Ws, d.Ho, d.Wo, d.P = h, w_, h, w_, N * h * w_
+    d.ksize, d.stride, d.pad, d.ups = 3, 1, 1, 0
+    d.W, d.Q, d.K, d.ldw = Wp.data_ptr(), cout, 9 * cin, 0
+    d.bias, d.act, d.out_scale = B16.data_ptr(), U.ACT["none"], 1.0
+    d.out, d.ldo, d.stats = out.data_ptr(), cout, stats.data_ptr()
+    assert lib.ladi_op_igemm(ctypes.byref(d), 1, cfg, stream_ptr()) == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    assert U.rel_l2(U.to_nchw(out), F.conv2d(x, wt, b, padding=1)) < TOL
+    o = out.float().reshape(N, -1, cout)
+    rps = h * w_ // 64                                   # one statistics row per wave = two 32-pixel row segments
+    st = stats[:N * rps].reshape(N, rps, cout, 2).sum(1).cpu()
+    assert U.rel_l2(st[..., 0], o.sum(1).cpu()) < 1e-4 and U.rel_l2(st[..., 1], (o * o).sum(1).cpu()) < 1e-4
+    # not whole blocks (W % 32, H % th) / not a stride-1 3x3: refused, never mis-computed
+    w3 = _rand((64, 64, 3, 3), 193)
+    for shp in ((1, 64, th, 48), (1, 64, th + 1, 32)):
+        with pytest.raises(AssertionError):
+            U.igemm(U.nhwc16(_rand(shp, 194)), U.pack_conv_weight(w3), 64, cfg=cfg)
+    with pytest.raises(AssertionError):
+        U.igemm(U.nhwc16(_rand((1, 64, 8, 32), 195)), U.pack_conv_weight(_rand((64, 64, 1, 1), 196)), 64, ksize=1, cfg=cfg)
 
 
 def test_conv3x3_stride2_pad1_and_asym():
