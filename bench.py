@@ -267,8 +267,11 @@ def traffic_committed(symbol):
         m = re.match(r"# lib_digest=(\w+)", lines[0]) if lines else None
         if not m or m.group(1) != lib_digest():
             return None, "committed PMC passes are stale (taken with another library build); re-run with --measure-traffic"
+        # rocprofv3 prints EVERY template argument of a kernel, the tile table's symbol only the leading ones ("igemm_halo_kernel<2, 2, 1, 3, 2, 24>"
+        # is "...<2, 2, 1, 3, 2, 24, 0, 0>" in a trace since the halo kernel grew defaulted arguments): match the argument list as a prefix
+        stem = symbol[:-1] if symbol.endswith(">") else symbol
         for line in lines[1:]:
-            if symbol in line:
+            if (stem + ">") in line or (stem + ",") in line:
                 vals[tag] = float(line.split()[-2]) * 1024.0   # avg KiB per dispatch -> bytes
                 break
     if len(vals) != 2:
