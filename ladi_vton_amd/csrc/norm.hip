@@ -191,7 +191,7 @@ constexpr int GNX_MAX_RPS = 96;     // more partial rows per sample than this: t
 __global__ __launch_bounds__(256) void gn_norm_kernel(const h16* __restrict__ src0, int C0, int ld0, const float* __restrict__ part0, int rps0,
                                                       const h16* __restrict__ src1, int C1, int ld1, const float* __restrict__ part1, int rps1,
                                                       int HW, int gs, const h16* __restrict__ gamma, const h16* __restrict__ beta, float eps,
-                                                      int silu, const h16* __restrict__ add, h16* __restrict__ out, int ppb, int* __restrict__ bad) {
+                                                      int silu, const h16* __restrict__ add, h16* __restrict__ out, int ppb, int* __restrict__ bad, int early) {
     __shared__ float rsum[256], rsq[256];
     __shared__ float csum[256], csq[256];
     __shared__ float gmean[GNX_CH + 2], grstd[GNX_CH + 2];
@@ -201,6 +201,29 @@ __global__ __launch_bounds__(256) void gn_norm_kernel(const h16* __restrict__ sr
     const int nch = min(GNX_CH, Ct - c0);
     const int g_lo = c0 / gs, g_hi = (c0 + nch - 1) / gs, ng = g_hi - g_lo + 1;
     const int cb = g_lo * gs, ncs = ng * gs;            // statistics channels [cb, cb + ncs): whole groups, <= 256
+    // streaming side: octet of the chunk, pixel lane (32 of them).  The FIRST round of data loads (up to four 16-byte pieces per thread) is
+    // issued before the statistics phase: it needs nothing from it, and its round trip then overlaps the one of the partial rows instead
+    // of following it (the statistics phase is ~2 us of every block's life, exposed once per launch because all blocks start together)
+    const int my_o = tid & 7, my_p = tid >> 3;
+    const int c = c0 + my_o * 8;
+    const bool live = c < Ct;
+    const h16* base = src0; int ld = ld0;
+    if (live) { if (c < C0) { base = src0 + c; ld = ld0; } else { base = src1 + (c - C0); ld = ld1; } }
+    const int pix0 = blockIdx.x * ppb;
+    const int npix = min(ppb, HW - pix0);
+    const size_t row0 = (size_t)n * HW + pix0;
+    const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    h16x8 ev[4] = {zero, zero, zero, zero}, ea[4] = {zero, zero, zero, zero};
+    if (live && early) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = my_p + 32 * k;
+            if (p < npix) {
+                ev[k] = *reinterpret_cast<const h16x8*>(base + (row0 + p) * ld);
+                if (add) ea[k] = *reinterpret_cast<const h16x8*>(add + (row0 + p) * Ct + c);
+            }
+        }
+    }
     {
         const int RL = 256 / ncs;                       // row lanes
         const int cl = tid % ncs, rl = tid / ncs;
@@ -239,9 +262,7 @@ __global__ __launch_bounds__(256) void gn_norm_kernel(const h16* __restrict__ sr
         }
         __syncthreads();
     }
-    const int my_o = tid & 7, my_p = tid >> 3;          // octet of the chunk, pixel lane (32 of them)
-    const int c = c0 + my_o * 8;
-    if (c >= Ct) return;
+    if (!live) return;
     float sc[8], sh[8];
     {
         const h16x8 ga = *reinterpret_cast<const h16x8*>(gamma + c), be = *reinterpret_cast<const h16x8*>(beta + c);
@@ -252,11 +273,6 @@ __global__ __launch_bounds__(256) void gn_norm_kernel(const h16* __restrict__ sr
             sh[e] = (float)be[e] - gmean[g] * sc[e];
         }
     }
-    const h16* base; int ld;
-    if (c < C0) { base = src0 + c; ld = ld0; } else { base = src1 + (c - C0); ld = ld1; }
-    const int pix0 = blockIdx.x * ppb;
-    const int npix = min(ppb, HW - pix0);
-    const size_t row0 = (size_t)n * HW + pix0;
     auto xform = [&](const h16x8& v, const h16x8& ad, const size_t row) {
         h16x8 o;
 #pragma unroll
@@ -268,8 +284,13 @@ __global__ __launch_bounds__(256) void gn_norm_kernel(const h16* __restrict__ sr
         }
         *reinterpret_cast<h16x8*>(out + row * Ct + c) = o;
     };
-    const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     int p = my_p;
+    if (early) {                                // the round loaded ahead of the statistics (early = 0: A/B switch LADI_GN_EARLY=0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (my_p + 32 * k < npix) xform(ev[k], ea[k], row0 + my_p + 32 * k);
+        p = my_p + 128;
+    }
     for (; p + 96 < npix; p += 128) {           // four independent 16-byte loads in flight (all loads of a round before its first store)
         const h16x8 v0 = *reinterpret_cast<const h16x8*>(base + (row0 + p) * ld);
         const h16x8 v1 = *reinterpret_cast<const h16x8*>(base + (row0 + p + 32) * ld);
@@ -473,8 +494,9 @@ int ladi_launch_gn_norm(const h16* src0, int C0, int ld0, const float* part0, in
     if (pin >= 32) ppb = pin;
     else while (ppb > 64 && (long long)n * chunks * ((HW + ppb - 1) / ppb) < 768) ppb >>= 1;
     dim3 grid((HW + ppb - 1) / ppb, n, chunks);
+    const char* ee = getenv("LADI_GN_EARLY");
     hipLaunchKernelGGL(gn_norm_kernel, grid, dim3(256), 0, st, src0, C0, ld0, part0, rps0, src1, C1, ld1, part1, rps1, HW, Ct / groups, gamma, beta,
-                       eps, silu, add, out, ppb, bad);
+                       eps, silu, add, out, ppb, bad, (ee && ee[0] == '0') ? 0 : 1);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 
