@@ -850,3 +850,101 @@ def test_committed_parity_record_is_one_run_and_holds_every_cited_key():
     missing = sorted(k for k in cited if k not in blob)
     assert not missing, missing
     assert len([k for k in blob if not k.startswith("_")]) >= 12, "a full GPU run records every measured tolerance, not a fragment"
+
+
+def test_one_pass_group_norm_chunk_math_emulation():
+    """Host-side replay of norm.hip gn_norm_kernel's index arithmetic (round 5): a block owns a 64-channel chunk, sums the partial rows of every
+    group that overlaps the chunk (groups straddle chunk boundaries and the boundary of the two concat sources; the last chunk may be ragged),
+    and applies scale / shift to its own channels only.  Replayed with the kernel's own formulas (row lanes, statistic-channel range
+    [g_lo gs, (g_hi + 1) gs)) in numpy and compared with GroupNorm over the virtual concat -- also in the 'direct' form (no partial rows: the
+    statistics come from the data), which the 48-pixel samples of the 8x6 level take."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+
+    def replay(x0, x1, groups, gamma, beta, eps, rows_px):
+        N, HW, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[2]
+        Ct, gs = C0 + C1, (C0 + C1) // groups
+        parts = []
+        for x in (x0, x1):
+            if x is None or rows_px == 0:
+                parts.append(None)
+                continue
+            rps = HW // rows_px
+            blk = x.reshape(N, rps, rows_px, x.shape[2])
+            parts.append(np.stack([blk.sum(2), (blk ** 2).sum(2)], -1))        # [N][rps][C][2]
+        out = np.zeros((N, HW, Ct))
+        for n in range(N):
+            for z in range((Ct + 63) // 64):
+                c0 = z * 64
+                nch = min(64, Ct - c0)
+                g_lo, g_hi = c0 // gs, (c0 + nch - 1) // gs
+                ng, cb = g_hi - g_lo + 1, g_lo * gs
+                ncs = ng * gs
+                assert ncs <= 256 and ng <= 66 and cb + ncs <= Ct
+                RL = 256 // ncs
+                rsum, rsq = np.zeros((RL, ncs)), np.zeros((RL, ncs))
+                for tid in range(256):
+                    cl, rl = tid % ncs, tid // ncs
+                    if rl >= RL:
+                        continue
+                    c = cb + cl
+                    src, part, clc = (x0, parts[0], c) if c < C0 else (x1, parts[1], c - C0)
+                    if part is not None:
+                        for r in range(rl, part.shape[1], RL):
+                            rsum[rl, cl] += part[n, r, clc, 0]; rsq[rl, cl] += part[n, r, clc, 1]
+                    else:
+                        for r in range(rl, HW, RL):
+                            rsum[rl, cl] += src[n, r, clc]; rsq[rl, cl] += src[n, r, clc] ** 2
+                csum, csq = rsum.sum(0), rsq.sum(0)
+                mean = np.array([csum[g * gs:(g + 1) * gs].sum() for g in range(ng)]) / (gs * HW)
+                var = np.maximum(np.array([csq[g * gs:(g + 1) * gs].sum() for g in range(ng)]) / (gs * HW) - mean ** 2, 0)
+                rstd = 1 / np.sqrt(var + eps)
+                for c in range(c0, c0 + nch):
+                    g = c // gs - g_lo
+                    sc = gamma[c] * rstd[g]
+                    src = x0[n, :, c] if c < C0 else x1[n, :, c - C0]
+                    out[n, :, c] = src * sc + (beta[c] - mean[g] * sc)
+        return out
+
+    for (C0, C1, groups, HW, rows_px) in ((320, 0, 32, 96, 32), (640, 320, 32, 64, 32), (160, 0, 32, 48, 0), (96, 32, 32, 48, 0), (1920, 640, 32, 48, 0)):
+        x0 = rng.normal(size=(2, HW, C0)) * 2 + 0.5
+        x1 = rng.normal(size=(2, HW, C1)) if C1 else None
+        gamma, beta = 1 + 0.1 * rng.normal(size=C0 + C1), 0.1 * rng.normal(size=C0 + C1)
+        got = replay(x0, x1, groups, gamma, beta, 1e-5, rows_px)
+        xc = np.concatenate([x0, x1], 2) if C1 else x0
+        xg = xc.reshape(2, HW, groups, -1)
+        ref = ((xg - xg.mean((1, 3), keepdims=True)) / np.sqrt(xg.var((1, 3), keepdims=True) + 1e-5)).reshape(2, HW, -1) * gamma + beta
+        assert np.abs(got - ref).max() < 1e-9, (C0, C1, HW)
+
+
+def test_halo_2d_block_addressing_emulation():
+    """Host-side replay of the 2-D blocked halo tile's addressing (igemm_halo.hip G2D, round 5): block pt -> (sample, block row, block column);
+    staged row i of the (TH + 2) x 34 block -> image pixel (or the zero frame); consumer row of output pixel (r, col) = (r + 1) 34 + col + 1; a tap
+    is the linear shift (dy - 1) 34 + (dx - 1).  For every output pixel and tap the staged value read must be the zero-padded 3x3 neighbour."""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    for (N, H, W, TH) in ((2, 16, 64, 8), (1, 8, 96, 4), (3, 4, 32, 4)):
+        img = rng.integers(1, 1000, size=(N, H, W)).astype(np.int64)
+        txn, tps = W // 32, (H // TH) * (W // 32)
+        HC = 34
+        for pt in range(N * tps):
+            n, t = pt // tps, pt % tps
+            ty, tx = t // txn, t % txn
+            y0, x0 = ty * TH, tx * 32
+            p0 = (n * H + y0) * W + x0
+            staged = np.zeros(((TH + 2) * HC + 64,), dtype=np.int64)           # rows beyond the block: zero-filled passes
+            for i in range((TH + 2) * HC):
+                rr, cc = i // HC, i % HC
+                y, x = y0 - 1 + rr, x0 - 1 + cc
+                if 0 <= y < H and 0 <= x < W:
+                    staged[i] = img[n, y, x]
+            for r in range(TH):                                                 # sub-tile r = image row y0 + r, epilogue pixel index p0 + r W + col
+                for col in range(32):
+                    rb = (r + 1) * HC + col + 1
+                    assert p0 + r * W + col == (n * H + y0 + r) * W + x0 + col
+                    for tap in range(9):
+                        dy, dx = tap // 3, tap % 3
+                        got = staged[rb + (dy - 1) * HC + (dx - 1)]
+                        y, x = y0 + r + dy - 1, x0 + col + dx - 1
+                        assert got == (img[n, y, x] if 0 <= y < H and 0 <= x < W else 0)
