@@ -15,6 +15,8 @@ contiguously over ranks (ladi_vton_amd.parallel.run_sharded), so results do not 
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --gpus N ...        (no launcher: bench.py re-executes itself under the torch.distributed.run line above, one rank per GPU)
+`--gpus N` always means N ranks: fewer visible GPUs than N, or a launcher that started another WORLD_SIZE, is exit code 2 and no line.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -82,6 +84,10 @@ def parse():
                         "summaries under profiles/ are taken from)")
     p.add_argument("--roofline-iters", type=int, default=4)
     p.add_argument("--no-tail", action="store_true", help="skip the D2H + PIL leg (with_d2h_pil_images_per_s)")
+    p.add_argument("--stub-step", action="store_true",
+                   help="rehearsal of the launch / sharding / collective / timing / reporting code WITHOUT the native pipeline: the step's compute is "
+                        "a per-row CPU function, the collective backend is gloo (tests/test_cpu.py drives `bench.py --gpus 2 --stub-step`); the printed "
+                        "line says data = 'stub' and can never be mistaken for a measurement")
     p.add_argument("--lanes", type=int, default=None,
                    help="sample-group lanes of the UNet forward inside the denoising loop (csrc/runtime.h UNetLanes); default: the library's "
                         "own choice (LADI_UNET_LANES, else 1: two concurrent half-batch forwards measured 3.5 % slower, DESIGN.md)")
@@ -360,76 +366,129 @@ def d2h_pil_tail(images_u8):
     return n
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def launch_ranks(a, argv):
+    """`--gpus N` is a promise about the number of ranks, not a label.  Called with --gpus N > 1 and no launcher around
+    it (no WORLD_SIZE in the environment), this process becomes the launcher: it replaces itself by `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` -- one rank per GPU -- after checking that the box has
+    N GPUs (exit code 2 and a message otherwise: one rank printing `n_gpus: 1` under a `--gpus 8` command line must not happen)."""
+    if not a.stub_step:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < a.gpus:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this box; one process per GPU is the only mode -- refusing to run "
+                             "fewer ranks than the command line promises\n" % (a.gpus, have))
+            sys.exit(2)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def stub_run_local(inp):
+    """--stub-step: a per-row CPU function of the row's tensors in place of producers + fused try-on (same stand-in as the gloo rehearsal
+    in tests/test_cpu.py) -- [b, H, W, 3] floats in [0, 1]"""
+    x = inp["image"].float() * 0.25 + inp["cloth"].float() * 0.25 + 0.5 + inp["noise_latents"].mean(dim=(1, 2, 3)).view(-1, 1, 1, 1) * 0.01
+    return x.permute(0, 2, 3, 1).clamp(0, 1).float().contiguous()
+
+
 def main():
     a = parse()
     cfg = CONFIGS[a.config]
+    if a.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        launch_ranks(a, sys.argv[1:])          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU: the native path has no CPU fallback"
-    torch.cuda.set_device(local_rank)          # bind the rank to its GPU before RCCL is initialised
-    dev = torch.device("cuda", local_rank)
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; the line's n_gpus would contradict the command line\n"
+                         % (a.gpus, world))
+        sys.exit(2)
+    stub = a.stub_step
+    if stub:
+        dev = torch.device("cpu")
+        a.no_roofline = a.no_cpu_baseline = a.no_tail = True
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU: the native path has no CPU fallback"
+        torch.cuda.set_device(local_rank)          # bind the rank to its GPU before RCCL is initialised
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if stub else "nccl", rank=rank, world_size=world)
     B = a.batch or cfg["batch"]
     H, W = a.height or cfg["H"], a.width or cfg["W"]
     steps_inf = a.inference_steps or cfg["steps"]
     scheduler = a.scheduler or cfg["scheduler"]
     producers = cfg["producers"]
 
-    import ladi_vton_amd as L
-    from ladi_vton_amd import _lib, configs as C
-    from ladi_vton_amd.parallel import run_sharded
+    from ladi_vton_amd import configs as C      # shapes / configuration tables only: imports without a GPU
     ucfg, vcfg = (C.UNET_FULL, C.VAE_FULL) if a.size == "full" else (C.UNET_TINY, C.VAE_TINY)
     ecfg = C.emasc_for_vae(vcfg)
     cfgs = dict(unet=ucfg, vae=vcfg, emasc=ecfg)
-    t_build = time.time()
-    want_cpu = (rank == 0 and world == 1 and not a.no_cpu_baseline and not a.roofline_only)
-    if want_cpu:   # the CPU baseline needs the fp32 checkpoint on the host; otherwise stream it tensor by tensor
-        sds = dict(unet=C.synth_state_dict(C.unet_shapes(ucfg), "unet."), vae=C.synth_state_dict(C.vae_shapes(vcfg), "vae."),
-                   emasc=C.synth_state_dict(C.emasc_shapes(ecfg), "emasc."))
-        unet, vae, emasc = L.NativeUNet(ucfg, sds["unet"]), L.NativeVAE(vcfg, sds["vae"]), L.NativeEMASC(ecfg, sds["emasc"])
-    else:
-        sds = None
-        unet = L.NativeUNet(ucfg, C.synth_items(C.unet_shapes(ucfg), "unet."))
-        vae = L.NativeVAE(vcfg, C.synth_items(C.vae_shapes(vcfg), "vae."))
-        emasc = L.NativeEMASC(ecfg, C.synth_items(C.emasc_shapes(ecfg), "emasc."))
-    vision = adapter = text = None
-    if producers and not a.roofline_only:
-        assert a.size == "full", "the producers are only wired for the released sizes"
-        vision = L.NativeCLIPVisionEncoder(C.VISION_FULL, C.synth_items(C.vision_shapes(C.VISION_FULL), "vision."))
-        adapter = L.NativeInversionAdapter(C.ADAPTER_FULL, C.synth_items(C.adapter_shapes(C.ADAPTER_FULL), "adapter."))
-        text = L.NativeCLIPTextEncoder(C.TEXT_FULL, C.synth_items(C.text_shapes(C.TEXT_FULL), "text."))
-    sch = {"ddim": L.DDIMScheduler, "pndm": L.PNDMScheduler, "lms": L.LMSDiscreteScheduler}[scheduler]()
-    pipe = L.StableDiffusionTryOnePipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, scheduler=sch, emasc=emasc,
-                                           emasc_int_layers=[1, 2, 3, 4, 5])
-    t_build = time.time() - t_build
     Ltok, D = 77, ucfg["cross_attention_dim"]
     global_B = B * world
     lo = rank * B
-    local = make_rows(lo, lo + B, H, W, Ltok, D, dev)      # this rank's rows of the global batch, resident in HBM before the timed region
-    if a.lanes is not None:
-        pipe.lanes = a.lanes
+    want_cpu = (rank == 0 and world == 1 and not a.no_cpu_baseline and not a.roofline_only)
+    t_build = time.time()
+    pipe = unet = sds = None
+    if stub:
+        run_local = stub_run_local
+    else:
+        import ladi_vton_amd as L
+        from ladi_vton_amd import _lib
+        if want_cpu:   # the CPU baseline needs the fp32 checkpoint on the host; otherwise stream it tensor by tensor
+            sds = dict(unet=C.synth_state_dict(C.unet_shapes(ucfg), "unet."), vae=C.synth_state_dict(C.vae_shapes(vcfg), "vae."),
+                       emasc=C.synth_state_dict(C.emasc_shapes(ecfg), "emasc."))
+            unet, vae, emasc = L.NativeUNet(ucfg, sds["unet"]), L.NativeVAE(vcfg, sds["vae"]), L.NativeEMASC(ecfg, sds["emasc"])
+        else:
+            unet = L.NativeUNet(ucfg, C.synth_items(C.unet_shapes(ucfg), "unet."))
+            vae = L.NativeVAE(vcfg, C.synth_items(C.vae_shapes(vcfg), "vae."))
+            emasc = L.NativeEMASC(ecfg, C.synth_items(C.emasc_shapes(ecfg), "emasc."))
+        vision = adapter = text = None
+        if producers and not a.roofline_only:
+            assert a.size == "full", "the producers are only wired for the released sizes"
+            vision = L.NativeCLIPVisionEncoder(C.VISION_FULL, C.synth_items(C.vision_shapes(C.VISION_FULL), "vision."))
+            adapter = L.NativeInversionAdapter(C.ADAPTER_FULL, C.synth_items(C.adapter_shapes(C.ADAPTER_FULL), "adapter."))
+            text = L.NativeCLIPTextEncoder(C.TEXT_FULL, C.synth_items(C.text_shapes(C.TEXT_FULL), "text."))
+        sch = {"ddim": L.DDIMScheduler, "pndm": L.PNDMScheduler, "lms": L.LMSDiscreteScheduler}[scheduler]()
+        pipe = L.StableDiffusionTryOnePipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, scheduler=sch, emasc=emasc,
+                                               emasc_int_layers=[1, 2, 3, 4, 5])
+        if a.lanes is not None:
+            pipe.lanes = a.lanes
 
-    def run_local(inp):
-        pe = inp["prompt_embeds"]
-        if producers:   # src/inference.py:267-295: in-shop cloth -> CLIP ViT-H/14 -> inversion adapter -> pseudo-word splice -> CLIP text encoder
-            feats = vision(L.clip_preprocess(inp["cloth"])).last_hidden_state     # resize + clamp + CLIP normalisation: one kernel
-            words = adapter(feats).reshape(feats.shape[0], 16, -1)
-            pe = L.encode_text_word_embedding(text, inp["word_ids"], words, 16).last_hidden_state
-        return pipe._run_fused(inp["image"], inp["mask_image"], inp["pose_map"], inp["warped_cloth"], pe, inp["negative_prompt_embeds"],
-                               inp["noise_cloth"], inp["noise_latents"], inp["noise_masked"], H, W, steps_inf, 7.5, 1.0, False, not a.no_graph,
-                               return_device=True, out_uint8=True)     # uint8 straight from the decode epilogue (numpy_to_pil rounding)
+        def run_local(inp):
+            pe = inp["prompt_embeds"]
+            if producers:   # src/inference.py:267-295: in-shop cloth -> CLIP ViT-H/14 -> inversion adapter -> pseudo-word splice -> CLIP text encoder
+                feats = vision(L.clip_preprocess(inp["cloth"])).last_hidden_state     # resize + clamp + CLIP normalisation: one kernel
+                words = adapter(feats).reshape(feats.shape[0], 16, -1)
+                pe = L.encode_text_word_embedding(text, inp["word_ids"], words, 16).last_hidden_state
+            return pipe._run_fused(inp["image"], inp["mask_image"], inp["pose_map"], inp["warped_cloth"], pe, inp["negative_prompt_embeds"],
+                                   inp["noise_cloth"], inp["noise_latents"], inp["noise_masked"], H, W, steps_inf, 7.5, 1.0, False, not a.no_graph,
+                                   return_device=True, out_uint8=True)     # uint8 straight from the decode epilogue (numpy_to_pil rounding)
+    t_build = time.time() - t_build
+    local = make_rows(lo, lo + B, H, W, Ltok, D, dev)      # this rank's rows of the global batch, resident in HBM before the timed region
 
     one_step = make_step(run_local, local, lo, B, global_B)   # contiguous row shards + the path's only collective (RCCL all-gather of uint8 images)
 
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
     def fence():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     if a.roofline_only:
         # context for the stand-alone UNet forwards; one untimed forward first (per-shape tile measurement happens there)
@@ -482,9 +541,9 @@ def main():
                 "what": "step + D2H of the uint8 batch + PIL.Image + JPEG(quality 95) encode of every image on rank 0 (inference.py:314-324)",
                 "jpeg_bytes_per_batch": nbytes}
     evals = steps_inf + (1 if scheduler == "pndm" else 0)
-    lib = _lib.load()
+    lib = None if stub else _lib.load()
     stage = (ctypes.c_float * 3)()
-    stage_ms = [float(stage[i]) for i in range(3)] if (pipe._tryon and lib.ladi_tryon_stage_ms(pipe._tryon, stage) == 0) else None
+    stage_ms = [float(stage[i]) for i in range(3)] if (pipe is not None and pipe._tryon and lib.ladi_tryon_stage_ms(pipe._tryon, stage) == 0) else None
     flop_img = TRYON_FLOP_PER_IMAGE.get((scheduler, steps_inf, H)) if a.size == "full" and W * 4 == H * 3 else None
 
     roofline = None
@@ -569,12 +628,13 @@ def main():
         line = {
             "metric": "try-on images/sec @%dx%d, %d %s steps" % (H, W, steps_inf, scheduler.upper()), "value": round(images_per_s, 4), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1000.0, 2) if a.steps else None, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic" if not stub else "stub (--stub-step: CPU stand-in compute over gloo; a rehearsal of launch / sharding / collective / timing, NOT a measurement)",
             "config": {"workload": "%s, %d %s steps (%d UNet evals, CFG 7.5), %dx%d, EMASC skips on, fp16 storage / fp32 accumulate, %s-size random-init "
                                    "checkpoint" % (cfg["name"], steps_inf, scheduler.upper(), evals, H, W, a.size),
                        "baseline_config_index": a.config, "batch_per_gpu": B, "global_batch": global_B, "producers_in_step": bool(producers),
                        "parallelism": "dp%d (contiguous row shards of the global batch + RCCL all-gather of uint8 images)" % world,
-                       "hipgraph": not a.no_graph, "unet_lanes": (lib.ladi_tryon_lanes(pipe._tryon) if pipe._tryon else None),
+                       "hipgraph": not a.no_graph, "unet_lanes": (lib.ladi_tryon_lanes(pipe._tryon) if (pipe is not None and pipe._tryon) else None),
                        "rccl_ranks_seen": rccl["ranks_seen"], "rccl_version": rccl["version"], "collective_backend": rccl["backend"]},
             "stage_ms_rank0": stage_ms, "model_build_s": round(t_build, 1),
             "with_d2h_pil_images_per_s": tail["images_per_s"] if tail else None, "d2h_pil_tail": tail,

@@ -333,8 +333,15 @@ int ladi_op_grid_sample_border(const void* src, int dtype, int B, int C, int H, 
  * (at most 10^8 = 1 s) on `stream` -- a side stream, next to the work being measured -- and writes {shader cycles, wall ticks} to
  * out2_dev (2 x uint64, device): cycles / ticks * 100 = the MHz the chip sustained under that load */
 int ladi_clock_probe(unsigned long long wall_ticks_100mhz, unsigned long long* out2_dev, void* stream);
-/* CLIP image pre-processing of the in-shop cloth in one pass (src/inference.py:268-272): resize((x + 1) / 2, (size, size), antialias)
- * .clamp(0, 1), then (v - mean[c]) / std[c]; src [B,3,H,W] in [-1,1] (dtype 0 fp32 / 1 fp16), dst fp16 [B,3,size,size]; mean3 / std3 host */
+/* CLIP image pre-processing of the in-shop cloth in one pass (src/inference.py:268-272): v = resize((x + 1) / 2, (size, size), antialias)
+ * .clamp(0, 1), then the processor's 8-bit round trip v = floor(v * 255) / 255, then (v - mean[c]) / std[c]; src [B,3,H,W] in [-1,1]
+ * (dtype 0 fp32 / 1 fp16), dst fp16 [B,3,size,size]; mean3 / std3 host.
+ * The round trip is what CLIPImageProcessor of the pinned transformers 4.27.3 (environment.yml:92) does to a FLOAT32 image on its way
+ * through to_pil_image -- i.e. the reference's default run (inference.py:186: weight_dtype = float32 unless --mixed_precision is given).
+ * It is applied for either input dtype: with --mixed_precision fp16 the reference hands the processor a float16 array, which 4.27.3's
+ * to_pil_image does not recognise as floating point (its isinstance test lists float / np.float32 / np.float64 only) and truncates
+ * without the x255 rescale -- a reference-side accident this library does not reproduce; 4.27.3 is not installable in the build image
+ * (5.x is), so neither branch could be run against the real processor here. */
 int ladi_op_clip_preprocess(const void* src, int dtype, int B, int H, int W, int size, const float* mean3, const float* std3, void* dst_f16,
                             void* stream);
 /* NHWC fp16 helpers of the refinement UNet: 2x2 max pooling, bilinear x2 upsampling with align_corners=True (C % 8 == 0) */

@@ -115,8 +115,10 @@ CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
 def clip_preprocess(cloth, size=224, mean=CLIP_MEAN, std=CLIP_STD):
-    """src/inference.py:268-272 in one kernel: resize((cloth + 1) / 2, (size, size), antialias=True).clamp(0, 1), CLIP mean / std
-    normalisation, fp16 pixel_values [B, 3, size, size] for the vision encoder.  cloth [B, 3, H, W] in [-1, 1], fp32 / fp16."""
+    """src/inference.py:268-272 in one kernel: resize((cloth + 1) / 2, (size, size), antialias=True).clamp(0, 1), the processor's 8-bit
+    round trip floor(v * 255) / 255 (transformers 4.27.3 CLIPImageProcessor on a float32 image: the reference's default, non-mixed-
+    precision run -- include/ladi_native.h says what is and is not emulated), CLIP mean / std normalisation, fp16 pixel_values
+    [B, 3, size, size] for the vision encoder.  cloth [B, 3, H, W] in [-1, 1], fp32 / fp16."""
     if cloth.dim() != 4 or cloth.shape[1] != 3:
         raise ValueError("expected a [B, 3, H, W] tensor")
     lib = _lib.load()

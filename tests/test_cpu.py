@@ -1,6 +1,7 @@
 """CPU-only tests: the oracle against the golden vectors / known-answer anchors, host logic of the product (schedulers,
 input validation, sharding) and the C-ABI surface (library loads, exports every declared symbol; no compute without a GPU)."""
 import ctypes
+import json
 import os
 from collections import OrderedDict
 import re
@@ -593,6 +594,35 @@ def test_bench_step_wiring_config3_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("OK %d" % r) in o, o
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus N` with no launcher around it must START N ranks (it re-executes itself under
+    torch.distributed.run, one process per GPU) -- never run one rank and print n_gpus 1.  Driven here with --stub-step (CPU stand-in
+    compute, gloo): the launch, WORLD_SIZE check, shard bounds, all-gather, barrier / MAX timing and the printed line are bench.py's own."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-step", "--steps", "2", "--warmup", "1", "--batch", "3",
+                        "--height", "32", "--width", "24"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks_seen"] == 2 and line["config"]["global_batch"] == 6
+    assert line["config"]["collective_backend"] == "gloo" and line["data"].startswith("stub")      # cannot be mistaken for a measurement
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
+    assert "dp2" in line["config"]["parallelism"]
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_gpus_flag():
+    """the two ways the line could contradict the command line: --gpus N on a box with fewer GPUs (here: none), and a launcher that
+    started another number of ranks than --gpus says -- both exit non-zero with a message and print no JSON line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 2 and "--gpus 2" in r.stderr and "{" not in r.stdout, (r.returncode, r.stdout, r.stderr)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--stub-step"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and "{" not in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
 def test_dataset_preprocessing_matches_real_reference_classes(tmp_path):
