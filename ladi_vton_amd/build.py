@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libladi_native.so")
-SOURCES = ["igemm.hip"] + ["igemm_inst_%s.hip" % g for g in "abcdefghi"] + ["igemm8.hip", "igemm_lc.hip", "igemm_halo.hip", "linear_xs.hip", "xf_fused.hip", "norm.hip", "attention.hip", "elementwise.hip", "f32path.hip", "runtime_core.cpp", "runtime_f32.cpp", "runtime_unet.cpp",
+SOURCES = ["igemm.hip"] + ["igemm_inst_%s.hip" % g for g in "abcdefghi"] + ["igemm8.hip", "igemm_lc.hip", "igemm_halo.hip"] + ["igemm_halo_inst_%s.hip" % g for g in "abcdefgh"] + ["linear_xs.hip", "xf_fused.hip", "norm.hip", "attention.hip", "elementwise.hip", "f32path.hip", "runtime_core.cpp", "runtime_f32.cpp", "runtime_unet.cpp",
            "runtime_vae.cpp", "runtime_text.cpp", "runtime_vision.cpp", "runtime_refine.cpp", "runtime_tps.cpp", "runtime_tryon.cpp", "capi.cpp"]
-HEADERS = ["common.h", "kernels.h", "igemm_common.h", "igemm_kernel.h", "igemm_tiles.h", "runtime.h", os.path.join("..", "..", "include", "ladi_native.h")]
+HEADERS = ["common.h", "kernels.h", "igemm_common.h", "igemm_kernel.h", "igemm_halo_kernel.h", "igemm_tiles.h", "runtime.h", os.path.join("..", "..", "include", "ladi_native.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function"]
 
 
@@ -69,30 +69,51 @@ def _write_atomic(path, text):
 def _build_locked(force, verbose, stamp, dig):
     hipcc = _hipcc()
 
-    hdr = hashlib.sha256()
-    for f in HEADERS:
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            hdr.update(fh.read())
-    hdr.update(" ".join(FLAGS).encode())
+    def obj_hash(src, deps):
+        h = hashlib.sha256()
+        for f in [os.path.join(CSRC, src)] + sorted(deps):
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+        h.update(" ".join(FLAGS).encode())
+        return h.hexdigest()
+
+    def read_deps(depfile):
+        """headers of THIS repo a translation unit included (hipcc -MD depfile, make syntax); system / ROCm headers are not tracked"""
+        try:
+            txt = open(depfile).read()
+        except OSError:
+            return None
+        root = os.path.dirname(HERE)
+        deps = set()
+        for tok in txt.split(":", 1)[-1].replace("\\\n", " ").split():
+            ap = os.path.abspath(tok)
+            if ap.startswith(root + os.sep) and ap.endswith(".h") and os.path.exists(ap):
+                deps.add(ap)
+        return deps
 
     def compile_one(src):
-        # per-object stamp = sha256(source + every header + flags): an unchanged translation unit is not recompiled
+        # per-object stamp = sha256(source + the repo headers it actually includes (depfile of its last compile) + flags): a header edit
+        # recompiles only the units that include it (round 6: every header used to be hashed into every unit -- ten minutes per edit)
         obj = os.path.join(OBJ, src + ".o")
-        h = hdr.copy()
-        with open(os.path.join(CSRC, src), "rb") as fh:
-            h.update(fh.read())
-        ostamp = obj + ".stamp"
-        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == h.hexdigest():
-            return obj
+        ostamp, odeps = obj + ".stamp", obj + ".d"
+        deps = read_deps(odeps)
+        if not force and deps is not None and os.path.exists(obj) and os.path.exists(ostamp):
+            try:
+                if open(ostamp).read() == obj_hash(src, deps):
+                    return obj
+            except OSError:
+                pass
         tmp = "%s.tmp%d.o" % (obj, os.getpid())
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", tmp]
+        tmpd = "%s.tmp%d.d" % (obj, os.getpid())
+        cmd = [hipcc] + FLAGS + ["-MD", "-MF", tmpd, "-c", os.path.join(CSRC, src), "-o", tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             sys.stderr.write(r.stderr)
         os.replace(tmp, obj)
-        _write_atomic(ostamp, h.hexdigest())
+        os.replace(tmpd, odeps)
+        _write_atomic(ostamp, obj_hash(src, read_deps(odeps) or set()))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:

@@ -1,7 +1,9 @@
 // extern "C" boundary of libladi_native (see include/ladi_native.h for the contract and reference citations).
 #include "../../include/ladi_native.h"
 #include "runtime.h"
+#include <mutex>
 #include <stdexcept>
+#include <vector>
 #include <cstring>
 #include <cmath>
 
@@ -590,30 +592,69 @@ int ladi_op_igemm(const ladi_igemm_desc* d, int batch, int tile_cfg, void* strea
         return rc;
     });
 }
+namespace {
+// Scratch of the op-level entry points: one grow-only buffer per (device, stream), never freed while the process lives.  Round 5's
+// ladi_op_group_norm did hipMalloc + hipStreamSynchronize + hipFree on EVERY call -- 0.27 ms for a 15 us kernel, which is what
+// profiles/r05_attn_bench.txt's "group_norm 0.17-0.86 TB/s" lines measured: every external caller of the C ABI paid it.
+struct OpScratch { int dev; hipStream_t st; float* p; size_t bytes; };
+float* op_scratch(hipStream_t st, size_t bytes) {
+    static std::vector<OpScratch> pool;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    for (auto& e : pool)
+        if (e.dev == dev && e.st == st) {
+            if (e.bytes >= bytes) return e.p;
+            HIP_OK(hipStreamSynchronize(st));                  // growing: the old buffer may still be read by work queued on this stream
+            (void)hipFree(e.p);
+            e.p = nullptr; e.bytes = 0;
+            HIP_OK(hipMalloc(reinterpret_cast<void**>(&e.p), bytes));
+            e.bytes = bytes;
+            return e.p;
+        }
+    OpScratch e{dev, st, nullptr, bytes};
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&e.p), bytes));
+    pool.push_back(e);
+    return e.p;
+}
+}  // namespace
+
 int ladi_op_group_norm(const void* src0, int C0, const void* src1, int C1, int n, int HW, int groups, const void* gamma, const void* beta,
                        float eps, int silu, const void* add, void* out, float* stats, void* stream) {
     return guarded("ladi_op_group_norm", [&]() {
         hipStream_t st = S(stream);
-        (void)stats;  // legacy scratch argument (unused: statistics are atomics-free partial rows now)
+        (void)stats;  // legacy scratch argument (unused: statistics are atomics-free partial rows in a per-stream scratch now)
         const int r0 = ladi_gn_partial_rows(n, HW, C0), r1 = C1 ? ladi_gn_partial_rows(n, HW, C1) : 0;
         const size_t f0 = (size_t)n * r0 * C0 * 2, f1 = (size_t)n * r1 * C1 * 2, fs = (size_t)n * (C0 + C1) * 2;
-        float* buf = nullptr;
-        HIP_OK(hipMalloc(reinterpret_cast<void**>(&buf), (f0 + f1 + fs) * sizeof(float)));
-        int rc = ladi_launch_gn_partial((const h16*)src0, C0, C0, n, HW, buf, st);
-        if (!rc && C1) rc = ladi_launch_gn_partial((const h16*)src1, C1, C1, n, HW, buf + f0, st);
-        if (!rc && ladi_gn_norm_direct(HW) && ladi_gn_norm_eligible(C0, 0, C1, 0, groups, HW)) {   // tiny samples: statistics from the data
+        const size_t g0 = (size_t)n * ladi_gn_reduce_rows() * C0 * 2, g1 = (size_t)n * ladi_gn_reduce_rows() * C1 * 2;
+        float* buf = op_scratch(st, (f0 + f1 + fs + g0 + g1) * sizeof(float));     // asynchronous: no allocation, no synchronisation per call
+        int rc = 0;
+        const bool direct = ladi_gn_norm_direct(HW) && ladi_gn_norm_eligible(C0, 0, C1, 0, groups, HW);
+        if (!direct) {
+            rc = ladi_launch_gn_partial((const h16*)src0, C0, C0, n, HW, buf, st);
+            if (!rc && C1) rc = ladi_launch_gn_partial((const h16*)src1, C1, C1, n, HW, buf + f0, st);
+        }
+        // the forms the runtime takes for the same operands (runtime_core.cpp group_norm): statistics from the data (tiny samples), partial rows
+        // folded first (many rows), one-pass; the three-stage form only where the one-pass kernel is not eligible
+        const float* p0 = buf; const float* p1 = buf + f0; int q0 = r0, q1 = r1;
+        const bool shape_ok = ladi_gn_norm_eligible(C0, 1, C1, C1 ? 1 : 0, groups, HW);
+        if (!rc && !direct && shape_ok) {
+            if (ladi_gn_reduce_eligible(C0, r0)) { rc = ladi_launch_gn_reduce(p0, C0, r0, n, buf + f0 + f1 + fs, st); p0 = buf + f0 + f1 + fs; q0 = ladi_gn_reduce_rows(); }
+            if (!rc && C1 && ladi_gn_reduce_eligible(C1, r1)) { rc = ladi_launch_gn_reduce(p1, C1, r1, n, buf + f0 + f1 + fs + g0, st); p1 = buf + f0 + f1 + fs + g0; q1 = ladi_gn_reduce_rows(); }
+        }
+        if (rc) return rc;
+        if (direct) {
             rc = ladi_launch_gn_norm((const h16*)src0, C0, C0, nullptr, 0, (const h16*)src1, C1, C1, nullptr, 0, n, HW, groups, (const h16*)gamma,
                                      (const h16*)beta, eps, silu, (const h16*)add, (h16*)out, st);
-        } else if (!rc && ladi_gn_norm_eligible(C0, r0, C1, r1, groups, HW)) {   // the form the runtime takes for the same operands (runtime_core.cpp group_norm)
-            rc = ladi_launch_gn_norm((const h16*)src0, C0, C0, buf, r0, (const h16*)src1, C1, C1, buf + f0, r1, n, HW, groups, (const h16*)gamma,
+        } else if (ladi_gn_norm_eligible(C0, q0, C1, q1, groups, HW)) {
+            rc = ladi_launch_gn_norm((const h16*)src0, C0, C0, p0, q0, (const h16*)src1, C1, C1, C1 ? p1 : nullptr, q1, n, HW, groups, (const h16*)gamma,
                                      (const h16*)beta, eps, silu, (const h16*)add, (h16*)out, st);
         } else {
-            if (!rc) rc = ladi_launch_gn_finalize(buf, C0, r0, buf + f0, C1, r1, n, HW, groups, (const h16*)gamma, (const h16*)beta, eps, buf + f0 + f1, st);
+            rc = ladi_launch_gn_finalize(buf, C0, r0, buf + f0, C1, r1, n, HW, groups, (const h16*)gamma, (const h16*)beta, eps, buf + f0 + f1, st);
             if (!rc) rc = ladi_launch_gn_apply((const h16*)src0, C0, C0, (const h16*)src1, C1, C1, n, HW, buf + f0 + f1, silu, (const h16*)add,
                                                (h16*)out, st);
         }
-        HIP_OK(hipStreamSynchronize(st));
-        (void)hipFree(buf);
         return rc;
     });
 }

@@ -268,13 +268,9 @@ int launch_cfg8(IGemmArgs a, int batch, hipStream_t st) {
     constexpr int BQ = 64 * TQ, BP = 128 * TP;
     constexpr int SMEM = 2 * (BQ + BP) * 64 * (int)sizeof(h16);
     static_assert(SMEM >= igemm_epilogue_lds_bytes<2, 4, TQ>(), "epilogue patches must fit in the staging buffers");
-    static bool attr_set = false;
+    static unsigned long long attr_done = 0;
     auto kfn = igemm8_kernel<TQ, TP, ABL>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
-            return -10;
-        attr_set = true;
-    }
+    if (ladi_ensure_dyn_lds(reinterpret_cast<const void*>(kfn), SMEM, attr_done)) return -10;
     const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
     int blocks = nq * np;
     a.tile_map = 0;

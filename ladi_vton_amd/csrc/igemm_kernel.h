@@ -20,7 +20,26 @@
 #include "kernels.h"
 #include "igemm_common.h"
 
+// Round 6: hipcc sinks the "prefetched" fragment reads of k-group kk + 1 behind the MFMAs of kk and keeps ONE register set (tools/r06/README.md
+// shows the ISA), so every MFMA waits for a ds_read issued one or two instructions earlier.  A sched_barrier on both sides of a k-group's
+// MFMAs pins the order the source states: reads of kk + 1 (and the interleaved DMA slice), then the MFMAs of kk.  Measured on the token-wise
+// projections (profiles/r06_ring_sched.txt): 0-2 %, inside the noise -- this kernel's K loop runs at the LDS-DMA fill rate, not at the
+// fragment-read latency -- so the pin is OFF in the library (-DLADI_RING_DOPIN builds the A/B arm of tools/r06/ring_sched.hip).
+#ifdef LADI_RING_DOPIN
+#define LADI_RING_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define LADI_RING_PIN() do { } while (0)
+#endif
+
+// Ablation switches for tools/r06/ring_sched.hip (-DLADI_RING_ABL=<mask>; the library never defines it): 1 = no DMA in the K loop, 2 = no fragment
+// ds_reads, 4 = no MFMAs, 8 = no per-step wait + barrier, 16 = no epilogue (one guarded store keeps the accumulators alive), 32 = empty kernel
+// (launch ramp + drain only), 64 = no prologue DMA either
+#ifndef LADI_RING_ABL
+#define LADI_RING_ABL 0
+#endif
+
 namespace {
+constexpr int RABL = LADI_RING_ABL;
 
 // WQ x WP waves, wave tile (TQ*32 channels) x (TP*32 pixels), K step BK, NST-stage LDS ring, OCC = minimum waves per SIMD the register
 // allocation must allow (2: two workgroups of 4 waves per CU; 1: one wave per SIMD with the whole 512-entry register file),
@@ -43,6 +62,7 @@ __global__ __launch_bounds__(64 * WQ * WP, OCC) void igemm_kernel(const IGemmArg
     static_assert(BQ % RPP == 0 && BP % RPP == 0, "tile rows must be a multiple of the rows per pass");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     h16* smem = reinterpret_cast<h16*>(smem_raw);
+    if constexpr (RABL & 32) { if (a.P >= 0) return; }
 
     const int tid = threadIdx.x;
     const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
@@ -195,21 +215,23 @@ __global__ __launch_bounds__(64 * WQ * WP, OCC) void igemm_kernel(const IGemmArg
     // ---- prologue: NST-1 stages in flight
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
-        if (s < nk) issue(s);
+        if (s < nk) { if constexpr (RABL & 64) advance(); else issue(s); }
 
     for (int kt = 0; kt < nk; ++kt) {
         // my part of stage kt has landed (later stages may stay in flight), then rendezvous: every wave's part of stage kt is
         // visible and every wave has finished reading the ring slot that is refilled next
         {
             const int later = min(NST - 2, nk - 1 - kt);   // stages issued after stage kt that may stay in flight
-            if (NST >= 5 && later >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * L) : "memory");
+            if constexpr (RABL & 8) { }
+            else if (NST >= 5 && later >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * L) : "memory");
             else if (NST >= 4 && later >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * L) : "memory");
             else if (NST >= 3 && later >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(L) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
         const bool more = kt + NST - 1 < nk;
         const int slot = (kt + NST - 1) % NST;
-        if constexpr (!ILV) { if (more) issue(slot); }
+        if constexpr (RABL & 1) { if (more) advance(); }
+        else if constexpr (!ILV) { if (more) issue(slot); }
         const h16* sW = smem + (kt % NST) * STAGE;
         const h16* sX = sW + BQ * BK;
         // fragments are double-buffered in registers: the ds_reads of k-group kk+1 (and, interleaved mode, a slice of the next stage's
@@ -219,6 +241,13 @@ __global__ __launch_bounds__(64 * WQ * WP, OCC) void igemm_kernel(const IGemmArg
         auto load_frags = [&](auto Kc) {
             constexpr int kk = decltype(Kc)::value;
             const int chunk = kk * 2 + hh;
+            if constexpr (RABL & 2) {
+#pragma unroll
+                for (int i = 0; i < TQ; ++i) asm volatile("" : "=v"(af[kk & 1][i]));
+#pragma unroll
+                for (int j = 0; j < TP; ++j) asm volatile("" : "=v"(bf[kk & 1][j]));
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < TQ; ++i) af[kk & 1][i] = *reinterpret_cast<const h16x8*>(sW + swz<BK>((wq * TQ + i) * 32 + l31, chunk));
 #pragma unroll
@@ -228,7 +257,8 @@ __global__ __launch_bounds__(64 * WQ * WP, OCC) void igemm_kernel(const IGemmArg
         static_for<0, NKK>([&](auto Kc) {
             constexpr int kk = decltype(Kc)::value;
             if constexpr (kk + 1 < NKK) load_frags(IntC<kk + 1>{});
-            if constexpr (ILV) {
+            LADI_RING_PIN();
+            if constexpr (ILV && !(RABL & 1)) {
                 // a 2-stage ring waits for the stage it issues in the SAME K step: front-load its DMA instructions into the first NKK-1
                 // k-groups so that the last of them has at least one group of MFMAs (~500 cycles) to land before the barrier
                 constexpr int G = (NST == 2 && NKK > 1) ? NKK - 1 : NKK;
@@ -241,11 +271,27 @@ __global__ __launch_bounds__(64 * WQ * WP, OCC) void igemm_kernel(const IGemmArg
             for (int i = 0; i < TQ; ++i)
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                {
+                    if constexpr (RABL & 4) asm volatile("" ::"v"(af[kk & 1][i]), "v"(bf[kk & 1][j]));
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                }
+            LADI_RING_PIN();
         });
         if constexpr (ILV) { if (more) advance(); }
     }
 
+    if constexpr (RABL & 16) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TQ; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 123.456f) reinterpret_cast<h16*>(a.out)[tid] = (h16)t;
+        return;
+    }
     igemm_epilogue<WQ, WP, TQ, TP>(a, acc, smem, q0, p0, pt, z, wave, lane);
 #endif
 }
@@ -256,13 +302,9 @@ int launch_cfg(IGemmArgs a, int batch, hipStream_t st) {
     constexpr int RING = NST * (BQ + BP) * BK * (int)sizeof(h16), EPI = igemm_epilogue_lds_bytes<WQ, WP, TQ>();
     constexpr int SMEM = RING > EPI ? RING : EPI;
     static_assert(SMEM <= 160 * 1024, "LDS budget of one CU");
-    static bool attr_set = false;
+    static unsigned long long attr_done = 0;
     auto kfn = igemm_kernel<WQ, WP, TQ, TP, BK, NST, OCC, ILV>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
-            return -10;
-        attr_set = true;
-    }
+    if (ladi_ensure_dyn_lds(reinterpret_cast<const void*>(kfn), SMEM, attr_done)) return -10;
     const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
     int blocks = nq * np;
     a.tile_map = 0;

@@ -195,13 +195,9 @@ int launch_lc(IGemmArgs a, int batch, hipStream_t st) {
     constexpr int SMEM = RING > EPI ? RING : EPI;
     static_assert(SMEM <= 160 * 1024, "LDS budget of one CU");
     if (a.ups || (batch != 1 && a.splitk <= 1)) return -16;
-    static bool attr_set = false;
+    static unsigned long long attr_done = 0;
     auto kfn = igemm_lc_kernel<WQ, WP, TQ, TP, NL, NST>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
-            return -10;
-        attr_set = true;
-    }
+    if (ladi_ensure_dyn_lds(reinterpret_cast<const void*>(kfn), SMEM, attr_done)) return -10;
     const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
     int blocks = nq * np;
     a.tile_map = 0;

@@ -79,6 +79,11 @@ int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int 
 // ladi_gn_norm_eligible) and applies -- no gn_finalize launch, no scale / shift table
 // (rps = 0 with a null part pointer: that source has no partial rows and the kernel sums the data itself -- samples of <= 64 pixels only,
 // ladi_gn_norm_direct)
+// round 6: fold the many partial rows of a VAE-sized tensor ([n][rps][C][2]) into ladi_gn_reduce_rows() rows per sample ([n][rows][C][2]),
+// after which ladi_launch_gn_norm takes it (rps > the one-pass kernel's row limit only)
+int ladi_gn_reduce_rows();
+bool ladi_gn_reduce_eligible(int C, int rps);
+int ladi_launch_gn_reduce(const float* part, int C, int rps, int n, float* out, hipStream_t st);
 bool ladi_gn_norm_direct(int HW);
 bool ladi_gn_norm_eligible(int C0, int rps0, int C1, int rps1, int groups, int HW);
 int ladi_launch_gn_norm(const h16* src0, int C0, int ld0, const float* part0, int rps0, const h16* src1, int C1, int ld1, const float* part1,

@@ -227,13 +227,36 @@ __global__ __launch_bounds__(256, (NST == 2 ? 3 : 2)) void linear_xs_kernel(cons
     // ---- bias of this slice -> LDS, last in the prologue (its wait drains everything above, which stage 0 needs anyway)
     for (int i = tid; i < qb_per_slice * 32; i += 256) bias_s[i] = a.bias ? a.bias[qb0 * 32 + i] : (h16)0.f;
 
+    // Round 6, GEGLU only: the accumulators of an output channel block start from the block's BIAS rows (lane = pixel column, register 4 g + e
+    // = row 8 g + 4 hh + e: four 8-byte broadcast reads per 32-row block, converted here) instead of zero, so the finished block needs no bias
+    // pass: the additions are gone and the conversions sit in front of the block's MFMAs instead of in the VALU-bound tail behind them.
+    // (fp32 rows in LDS would save the conversions too, but push the three-workgroup form of the 64x48-level GEGLU past its 53 KB.)  The plain
+    // and residual forms keep "sum, then + bias": they are not VALU-bound, and the residual form is tested BIT-equal to the tiled kernels' epilogue.
+    constexpr bool BIAS_INIT = (MODE == 2);
     f32x16 acc[HALVES][PB];
+    auto acc_init = [&](int wblk) {      // wblk: first 32-row weight block (inside this slice) of the output block about to be accumulated
+        if constexpr (!BIAS_INIT) {
 #pragma unroll
-    for (int h = 0; h < HALVES; ++h)
+            for (int h = 0; h < HALVES; ++h)
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb)
+                for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[h][pb][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[h][pb][r] = 0.f;
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+            const h16* bp = bias_s + (wblk + h) * 32 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const h16x4 b4 = *reinterpret_cast<const h16x4*>(bp + 8 * g);
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[h][pb][4 * g + e] = (float)b4[e];
+            }
+        }
+    };
 
     h16* outp = reinterpret_cast<h16*>(a.out);
     // swizzled A-fragment addresses: chunk (2*k16 + hh) ^ swz == ((2*k16) & ~7) + (((2*k16) & 7) ^ t) with t = hh ^ swz, so four
@@ -252,9 +275,10 @@ __global__ __launch_bounds__(256, (NST == 2 ? 3 : 2)) void linear_xs_kernel(cons
             if (s == 0) {
                 // prologue: X panel, bias, stages 0 and 1, first residual.  The builtin (not asm) form lets the compiler's own
                 // scoreboard see that the X-panel loads have landed; otherwise it re-waits for them down to vmcnt(0) inside stage 0
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+                __builtin_amdgcn_s_waitcnt(BIAS_INIT ? 0x0070 : 0x0F70);   // vmcnt(0) (+ lgkmcnt(0): the bias rows are read right behind the barrier)
             } else wait_vm_n(vm_issued - m_cur);      // stage s has landed (everything issued after it may stay in flight)
             asm volatile("s_barrier" ::: "memory");
+            if (s == 0) acc_init(0);                  // the bias rows are in LDS behind the first barrier
             if (NST == 3) m_cur = m_next;
             if (MODE == 1 && sub == 0 && ob + 1 < ob0 + nblk) { issue_res(ob + 1); mr_next = vm_issued; }
             if (NST == 3) { if (s + 2 < nstage) { issue_w(s + 2); m_next = vm_issued; } }
@@ -269,7 +293,7 @@ __global__ __launch_bounds__(256, (NST == 2 ? 3 : 2)) void linear_xs_kernel(cons
             }
             if (sub == SUB - 1) {
                 // ---- output channel block finished: bias (+ residual | GEGLU gate), fp16, transpose through LDS, 16-byte stores
-                const h16* bsl = bias_s + (s0 / KH) * 32;   // bias rows of this block's first weight block
+                const h16* bsl = bias_s + (s0 / KH) * 32;   // bias rows of this block's first weight block (plain / residual forms)
                 if (MODE == 1) {
                     wait_vm_n(vm_issued - mr_cur);          // this block's residual tile has landed in the wave's buffer
                     mr_cur = mr_next;
@@ -304,14 +328,12 @@ __global__ __launch_bounds__(256, (NST == 2 ? 3 : 2)) void linear_xs_kernel(cons
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int lc = 8 * g + 4 * hh;
-                            const h16x4 b4 = *reinterpret_cast<const h16x4*>(bsl + lc);
                             h16x4 o;
                             if (MODE == 2) {
-                                const h16x4 g4 = *reinterpret_cast<const h16x4*>(bsl + 32 + lc);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    o[e] = (h16)((acc[0][pb][4 * g + e] + (float)b4[e]) * gelu_f(acc[HALVES - 1][pb][4 * g + e] + (float)g4[e]));
+                                for (int e = 0; e < 4; ++e) o[e] = (h16)(acc[0][pb][4 * g + e] * gelu_f(acc[HALVES - 1][pb][4 * g + e]));
                             } else {
+                                const h16x4 b4 = *reinterpret_cast<const h16x4*>(bsl + lc);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) o[e] = (h16)(acc[0][pb][4 * g + e] + (float)b4[e]);
                             }
@@ -328,12 +350,7 @@ __global__ __launch_bounds__(256, (NST == 2 ? 3 : 2)) void linear_xs_kernel(cons
                     }
                 }
                 vm_issued += STORES;
-#pragma unroll
-                for (int h = 0; h < HALVES; ++h)
-#pragma unroll
-                    for (int pb = 0; pb < PB; ++pb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[h][pb][r] = 0.f;
+                acc_init((s0 + SUB) / KH < qb_per_slice ? (s0 + SUB) / KH : 0);      // next block's bias rows (the last block re-reads block 0: unused)
             }
         });
     }
@@ -345,11 +362,8 @@ int launch_xs_ln(const IGemmArgs& a, int qs, hipStream_t st) {
     const int smem = NST * XS_STAGE + 4 * (MODE == 1 ? 2 * XS_RPATCH : XS_PATCH) + ((qb_per_slice * 32 * 2 + 15) & ~15) + (PRE == 2 ? KH * XS_KB * 8 : 0);
     if (smem > (NST == 2 ? XS_SMEM_MAX3 : XS_SMEM_MAX)) return -10;
     auto kfn = linear_xs_kernel<KH, PB, MODE, PRE, NST>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, NST == 2 ? XS_SMEM_MAX3 : XS_SMEM_MAX) != hipSuccess) return -10;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (ladi_ensure_dyn_lds(reinterpret_cast<const void*>(kfn), NST == 2 ? XS_SMEM_MAX3 : XS_SMEM_MAX, attr_done)) return -10;
     dim3 grid((unsigned)(a.P / (128 * PB)), (unsigned)qs);
     hipLaunchKernelGGL(kfn, grid, dim3(256), smem, st, a, qb_per_slice);
     return hipGetLastError() == hipSuccess ? 0 : -11;

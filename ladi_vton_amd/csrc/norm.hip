@@ -177,6 +177,45 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ s
     }
 }
 
+// Round 6: partial rows of the VAE-sized tensors.  At 512x384 a producer's epilogue writes one row per 32 or 64 pixels -- 3 072-6 144 rows of
+// [C][2] floats per sample, 50 MB for C = 128 at batch 8 -- and gn_finalize walked them with 8 + (n, 4 groups) blocks of strided 8-byte loads:
+// 52.6 us x 62 launches per step, pure tail (profiles/r05_vae_kernel_stats.txt).  This kernel folds them, fully coalesced (a row is C * 8
+// contiguous bytes), into R2 rows per sample -- block (b, n) sums rows [b rps / R2, (b + 1) rps / R2) in order: fixed association, bitwise
+// reproducible -- after which the ONE-pass kernel below takes the tensor like any UNet-sized one (R2 <= GNX_MAX_RPS).
+__global__ __launch_bounds__(256) void gn_reduce_rows_kernel(const float* __restrict__ part, int C, int rps, int r2, float* __restrict__ out) {
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x, b = blockIdx.x, n = blockIdx.y;
+    const int q = C >> 1;                               // float4 pieces per row (two channels each); launcher: q <= 256 or a multiple of 256
+    const int lanes = q < 256 ? 256 / q : 1;            // row lanes
+    const int r_lo = (int)((long long)b * rps / r2), r_hi = (int)((long long)(b + 1) * rps / r2);
+    for (int q0 = 0; q0 < q; q0 += 256) {
+        const int qi = q0 + (q < 256 ? tid % q : tid), rl = q < 256 ? tid / q : 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < lanes && qi < q) {
+            const float4* row = reinterpret_cast<const float4*>(part) + ((size_t)n * rps) * q + qi;
+            int r = r_lo + rl;
+            for (; r + 3 * lanes < r_hi; r += 4 * lanes) {          // four independent 16-byte loads in flight
+                const float4 a0 = row[(size_t)r * q], a1 = row[(size_t)(r + lanes) * q], a2 = row[(size_t)(r + 2 * lanes) * q], a3 = row[(size_t)(r + 3 * lanes) * q];
+                acc.x += (a0.x + a1.x) + (a2.x + a3.x); acc.y += (a0.y + a1.y) + (a2.y + a3.y);
+                acc.z += (a0.z + a1.z) + (a2.z + a3.z); acc.w += (a0.w + a1.w) + (a2.w + a3.w);
+            }
+            for (; r < r_hi; r += lanes) { const float4 a0 = row[(size_t)r * q]; acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w; }
+        }
+        if (lanes > 1) {
+            __syncthreads();
+            red[tid] = acc;
+            __syncthreads();
+            if (tid < q) {
+                float4 t = red[tid];
+                for (int l = 1; l < lanes; ++l) { const float4 u = red[l * q + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+                reinterpret_cast<float4*>(out)[((size_t)n * r2 + b) * q + tid] = t;
+            }
+        } else if (qi < q) {
+            reinterpret_cast<float4*>(out)[((size_t)n * r2 + b) * q + qi] = acc;
+        }
+    }
+}
+
 // GroupNorm in ONE pass over the data (round 5): finalize folded into apply.  Block = (pixel block, sample, 64-channel chunk): the block sums the
 // partial rows of the groups that overlap its chunk itself (at most 64 + 2 gs - 2 channels x rps rows of 8 bytes, L2-resident: the producer's
 // epilogue wrote them a moment ago), derives scale / shift for its 64 channels and streams its 128-byte row pieces.  Removes the gn_finalize
@@ -462,6 +501,18 @@ int ladi_launch_gn_apply(const h16* src0, int C0, int ld0, const h16* src1, int 
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
 
+// rows per sample the fold leaves (ladi_launch_gn_reduce): few enough for the one-pass kernel's per-block re-summation to be noise beside its data
+int ladi_gn_reduce_rows() { return 16; }
+bool ladi_gn_reduce_eligible(int C, int rps) {
+    const char* e = getenv("LADI_GN_REDUCE");        // =0: the three-stage form as in round 5 (A/B)
+    return !(e && e[0] == '0') && !(C & 1) && rps > GNX_MAX_RPS;
+}
+int ladi_launch_gn_reduce(const float* part, int C, int rps, int n, float* out, hipStream_t st) {
+    if (!ladi_gn_reduce_eligible(C, rps) || (reinterpret_cast<uintptr_t>(part) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return -1;
+    hipLaunchKernelGGL(gn_reduce_rows_kernel, dim3(ladi_gn_reduce_rows(), n), dim3(256), 0, st, part, C, rps, ladi_gn_reduce_rows(), out);
+    return hipGetLastError() == hipSuccess ? 0 : -11;
+}
+
 bool ladi_gn_norm_direct(int HW) {
     const char* e = getenv("LADI_GN_DIRECT");        // =0: always gn_partial (A/B)
     return HW <= GNX_DIRECT_HW && !(e && e[0] == '0');
@@ -490,7 +541,9 @@ int ladi_launch_gn_norm(const h16* src0, int C0, int ld0, const float* part0, in
     // pixels per block: 128-byte row pieces x ppb rows; halve until the grid has ~3 blocks per CU (LADI_GN_PPB pins it: sweeps)
     const char* pe = getenv("LADI_GN_PPB");
     const int pin = pe ? atoi(pe) : 0;
-    int ppb = 512;
+    // (round 6: VAE-sized tensors reach this kernel behind ladi_launch_gn_reduce -- larger pixel blocks there, so that a block's re-summation
+    // of the partial rows, <= 16 rows x ~70 channels, stays ~1 % of the bytes it streams)
+    int ppb = HW >= 32768 ? 2048 : 512;
     if (pin >= 32) ppb = pin;
     else while (ppb > 64 && (long long)n * chunks * ((HW + ppb - 1) / ppb) < 768) ppb >>= 1;
     dim3 grid((HW + ppb - 1) / ppb, n, chunks);

@@ -145,6 +145,7 @@ struct UNet {
     std::vector<XfBlock> down_xf, up_xf; XfBlock mid_xf;
     DConv down_samp[3], up_samp[3];
     int temb_total = 0;
+    int xf_fuse = 0;                        // LADI_XF_FUSE, latched at load(): fused attn2 / feed-forward kernels of the C = 320 level (default off)
     // context (cross-attention K/V) cache
     int ctx_n = 0, ctx_L = 0, ctx_cap_n = 0, ctx_cap_samples = 0;    // cache capacity in rows (n * L) and, for the per-sample tiles, in samples
     std::unique_ptr<DevPool> ctx_pool;

@@ -293,6 +293,20 @@ Act group_norm(Ctx& c, const DNorm& nm, const Act& x, const Act* x2, int groups,
     const int gs = (C0 + C1) / groups;
     const bool onepass_shape = ladi_gn_norm_eligible(C0, 1, C1, C1 ? 1 : 0, groups, HW) && gs * groups == C0 + C1;
     GnParts g = gn_parts(c, x, x2, onepass_shape);
+    // VAE-sized tensors (thousands of partial rows per sample): fold the rows first (one small coalesced kernel per source), then the one-pass
+    // kernel -- instead of gn_finalize's strided walk over 50 MB of rows (52.6 us x 62 per step in round 5).  The scratch is reserved whichever
+    // form runs (planning pass == real pass).
+    {
+        const Act* srcs[2] = {&x, x2};
+        for (int i = 0; i < 2; ++i) {
+            if (!srcs[i]) continue;
+            float* folded = c.alloc_f32((size_t)x.n * ladi_gn_reduce_rows() * srcs[i]->c * 2);
+            if (onepass_shape && g.part[i] && ladi_gn_reduce_eligible(srcs[i]->c, g.rps[i])) {
+                if (!c.dry()) c.check(ladi_launch_gn_reduce(g.part[i], srcs[i]->c, g.rps[i], x.n, folded, c.st), "gn_reduce");
+                g.part[i] = folded; g.rps[i] = ladi_gn_reduce_rows();
+            }
+        }
+    }
     if (c.dry()) return out;
     if (ladi_gn_norm_eligible(C0, g.rps[0], C1, g.rps[1], groups, HW)) {
         // few partial rows per sample (every UNet level): each block finalises its own 64-channel chunk -- one launch instead of two

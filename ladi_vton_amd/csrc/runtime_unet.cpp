@@ -24,7 +24,7 @@ static ResBlock load_res(DevPool& pool, const WeightStore& ws, const std::string
     return r;
 }
 
-static XfBlock load_xf(DevPool& pool, const WeightStore& ws, const std::string& p, int heads) {
+static XfBlock load_xf(DevPool& pool, const WeightStore& ws, const std::string& p, int heads, bool pack_fused) {
     XfBlock x;
     x.gn = load_norm(pool, ws, p + ".norm");
     x.proj_in = load_conv(pool, ws, p + ".proj_in");
@@ -43,8 +43,9 @@ static XfBlock load_xf(DevPool& pool, const WeightStore& ws, const std::string& 
     x.C = x.proj_in.cout;
     x.heads = heads;
     if (x.C != heads * 64) throw std::runtime_error(p + ": head_dim must be 64");
-    // the C = 320 level runs attn2 and the feed-forward as fused kernels (xf_fused.hip): pack to_out / ff.net.2 per head / per hidden block
-    if (ladi_xf_fused_eligible(x.C, heads, 128, 1) && x.o2.cin_pad == x.C && x.ff2.cin_pad == 4 * x.C && x.ff1.cout == 8 * x.C) {
+    // the C = 320 level CAN run attn2 and the feed-forward as fused kernels (xf_fused.hip, default off): pack to_out / ff.net.2 per head / per
+    // hidden block -- only when the path is switched on (UNet::xf_fuse): the default path reads none of it
+    if (pack_fused && ladi_xf_fused_eligible(x.C, heads, 128, 1) && x.o2.cin_pad == x.C && x.ff2.cin_pad == 4 * x.C && x.ff1.cout == 8 * x.C) {
         x.o2_packed = reinterpret_cast<h16*>(pool.alloc(ladi_xf_wo_packed_elems() * sizeof(h16)));
         x.ff2_packed = reinterpret_cast<h16*>(pool.alloc(ladi_xf_w2_packed_elems() * sizeof(h16)));
         if (ladi_launch_pack_wo(x.o2.w, x.o2_packed, nullptr) || ladi_launch_pack_w2(x.ff2.w, x.ff2_packed, nullptr) || hipDeviceSynchronize() != hipSuccess)
@@ -55,6 +56,10 @@ static XfBlock load_xf(DevPool& pool, const WeightStore& ws, const std::string& 
 
 void UNet::load(const UNetCfg& c, const WeightStore& ws) {
     cfg = c;
+    // LADI_XF_FUSE (0 / 1 / 2: none / attn2 only / attn2 + feed-forward as fused kernels) is latched HERE, once per UNet: the value selects
+    // different arena allocations in the forward, so a planning pass, its real pass, a later re-plan and the lanes of one forward must all
+    // see the same one (it used to be a getenv in every block of every pass)
+    { const char* e = getenv("LADI_XF_FUSE"); xf_fuse = e ? atoi(e) : 0; }
     const int L = c.layers_per_block;
     conv_in = load_conv(pool, ws, "conv_in", c.in_channels);
     time_l1 = load_conv(pool, ws, "time_embedding.linear_1");
@@ -71,18 +76,18 @@ void UNet::load(const UNetCfg& c, const WeightStore& ws) {
         for (int j = 0; j < L; ++j) {
             const std::string p = "down_blocks." + std::to_string(i);
             add_res(&down_res, nullptr, p + ".resnets." + std::to_string(j));
-            if (i < 3) down_xf.push_back(load_xf(pool, ws, p + ".attentions." + std::to_string(j), c.heads[i]));
+            if (i < 3) down_xf.push_back(load_xf(pool, ws, p + ".attentions." + std::to_string(j), c.heads[i], xf_fuse > 0));
         }
         if (i < 3) down_samp[i] = load_conv(pool, ws, "down_blocks." + std::to_string(i) + ".downsamplers.0.conv");
     }
     add_res(nullptr, &mid_res[0], "mid_block.resnets.0");
-    mid_xf = load_xf(pool, ws, "mid_block.attentions.0", c.heads[3]);
+    mid_xf = load_xf(pool, ws, "mid_block.attentions.0", c.heads[3], xf_fuse > 0);
     add_res(nullptr, &mid_res[1], "mid_block.resnets.1");
     for (int i = 0; i < 4; ++i) {
         for (int j = 0; j < L + 1; ++j) {
             const std::string p = "up_blocks." + std::to_string(i);
             add_res(&up_res, nullptr, p + ".resnets." + std::to_string(j));
-            if (i > 0) up_xf.push_back(load_xf(pool, ws, p + ".attentions." + std::to_string(j), c.heads[3 - i]));
+            if (i > 0) up_xf.push_back(load_xf(pool, ws, p + ".attentions." + std::to_string(j), c.heads[3 - i], xf_fuse > 0));
         }
         if (i < 3) up_samp[i] = load_conv(pool, ws, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv");
     }
@@ -225,15 +230,12 @@ struct Fwd {
         ConvOpt or1; or1.res0 = &t0;
         Act t1 = conv2d(c, b.o1, o1, nullptr, or1);
         // attn2 and the feed-forward as ONE kernel each on the C = 320 level (xf_fused.hip; LADI_XF_FUSE=0 / =1 / =2: none / attn2 only / both,
-        // read per call so that a planning pass and its real pass agree and one process can A/B), else the chain of projections.  Measured on
+        // latched at UNet::load), else the chain of projections.  Measured on
         // MI355X (profiles/r05_xf_fused_ab.txt): parity-green and bit-reproducible, but at one wave per SIMD the fused chains expose the latency two
         // waves per SIMD hide in the separate launches -- attn2 85.7 us against the ~76 us of the three launches it replaces (forward
         // +0.05 ms), feed-forward 275 us against 109 + 57 us (forward +0.45 ms) -- so the DEFAULT IS OFF; the kernels stay selectable.
         int fuse = 0;
-        if (b.o2_packed && b.kp_tiles && t1.ld == C && ladi_xf_fused_eligible(C, b.heads, T, u.ctx_L)) {
-            const char* e = getenv("LADI_XF_FUSE");
-            fuse = e ? atoi(e) : 0;
-        }
+        if (b.o2_packed && b.kp_tiles && t1.ld == C && ladi_xf_fused_eligible(C, b.heads, T, u.ctx_L)) fuse = u.xf_fuse;
         Act t2;
         if (fuse >= 1) {
             t2 = c.new_act(n, T, 1, C);

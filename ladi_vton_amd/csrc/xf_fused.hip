@@ -714,11 +714,8 @@ bool ladi_xf_fused_eligible(int C, int heads, int T, int L) { return C == xa::C 
 int ladi_launch_xattn_block(const XAttnBlockArgs& a, hipStream_t st) {
     if (a.P <= 0 || (a.P % 128) || a.T <= 0 || (a.T % 128) || (a.P % a.T) || a.nk < 1 || a.nk > xa::NKP) return -1;
     if (((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.Wq | (uintptr_t)a.Kp | (uintptr_t)a.Vt | (uintptr_t)a.Wo) & 15) return -4;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(xa::xattn_full_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, xa::SMEM) != hipSuccess) return -10;
-        attr = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (ladi_ensure_dyn_lds(reinterpret_cast<const void*>(xa::xattn_full_kernel), xa::SMEM, attr_done)) return -10;
     hipLaunchKernelGGL(xa::xattn_full_kernel, dim3((unsigned)(a.P / 128)), dim3(256), xa::SMEM, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }
@@ -728,12 +725,9 @@ int ladi_launch_ff_block(const FFBlockArgs& a, hipStream_t st) {
     if (((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.W1 | (uintptr_t)a.W2) & 15) return -4;
     const char* e = getenv("LADI_FF_PIPE");         // read per call: one process can run both loop forms (tests, A/B)
     const bool pipe = !(e && e[0] == '0');
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn::ff_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, ffn::SMEM) != hipSuccess) return -10;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn::ff_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ffn::SMEM) != hipSuccess) return -10;
-        attr = true;
-    }
+    static unsigned long long attr_done0 = 0, attr_done1 = 0;
+    if (ladi_ensure_dyn_lds(reinterpret_cast<const void*>(ffn::ff_fused_kernel<0>), ffn::SMEM, attr_done0)) return -10;
+    if (ladi_ensure_dyn_lds(reinterpret_cast<const void*>(ffn::ff_fused_kernel<1>), ffn::SMEM, attr_done1)) return -10;
     if (pipe) hipLaunchKernelGGL(ffn::ff_fused_kernel<1>, dim3((unsigned)(a.P / 128)), dim3(256), ffn::SMEM, st, a);
     else hipLaunchKernelGGL(ffn::ff_fused_kernel<0>, dim3((unsigned)(a.P / 128)), dim3(256), ffn::SMEM, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -11;

@@ -4,7 +4,7 @@
 // (cross-compiled, the binaries travel with the snapshot), run on the GPU box by tools/r05/call7.sh.
 //   mask 0 full | 1 no weight DMA | 2 no halo DMA | 3 no DMA at all | 4 no fragment reads | 8 no MFMA | 16 no wait + barrier | combinations
 #define LADI_HALO_TOOL 1
-#include "../../ladi_vton_amd/csrc/igemm_halo.hip"
+#include "../../ladi_vton_amd/csrc/igemm_halo_kernel.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

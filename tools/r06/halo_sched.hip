@@ -1,0 +1,98 @@
+// Round 6: instruction-schedule experiments on the dominant kernel of the UNet forward, igemm_halo_kernel<2,2,1,3,2,24> (128x128 tile, 4 waves, two
+// workgroups per CU).  The kernel source is the library's (igemm_halo.hip) compiled with -DLADI_HALO_PIN=0|1 (the library's switch), or -- with
+// tools/experiments/halo_sched_variants.patch applied -- with -DLADI_HALO_SCHED=<variant> (the forms of GPU calls 1-3, 5); this harness runs the 3x3
+// convolution 640 -> 640 at 32x24, n = 16 (P = 12 288, K = 5 760; 90.6 GFLOP), CHECKS the result against a CPU reference on sampled outputs and
+// against a second launch (bit-equal), and times 30 launches with HIP events.
+#define LADI_HALO_TOOL 1
+#ifndef LADI_HALO_SCHED
+#define LADI_HALO_SCHED (100 + LADI_HALO_PIN)      /* library source: report the pin switch (99 = the library's own choice) */
+#endif
+#include "../../ladi_vton_amd/csrc/igemm_halo_kernel.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+#ifndef HS_TQ
+#define HS_TQ 2
+#define HS_TP 2
+#define HS_NXB 1
+#define HS_NSTW 3
+#define HS_WPN 2
+#define HS_WMAX 24
+#endif
+
+int main(int argc, char** argv) {
+    const int n = 16, H = argc > 1 ? atoi(argv[1]) : 32, W = argc > 2 ? atoi(argv[2]) : 24, C = argc > 3 ? atoi(argv[3]) : 640, Q = argc > 4 ? atoi(argv[4]) : 640;
+    const int splitk = argc > 5 ? atoi(argv[5]) : 1;
+    const int P = n * H * W, K = 9 * C;
+    std::vector<h16> hx((size_t)P * C), hw((size_t)Q * K), hb(Q), hr((size_t)P * Q);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((float)((s >> 9) & 0xffff) / 65536.f - 0.5f); };
+    for (auto& v : hx) v = (h16)(rnd() * 2.f);
+    for (auto& v : hw) v = (h16)(rnd() * 0.05f);
+    for (auto& v : hb) v = (h16)rnd();
+    for (auto& v : hr) v = (h16)rnd();
+    h16 *dx, *dw, *db, *dout, *dres; float* dws; int* dcnt;
+    CK(hipMalloc((void**)&dx, hx.size() * 2)); CK(hipMalloc((void**)&dw, hw.size() * 2)); CK(hipMalloc((void**)&db, hb.size() * 2));
+    CK(hipMalloc((void**)&dout, (size_t)P * Q * 2)); CK(hipMalloc((void**)&dres, (size_t)P * Q * 2));
+    CK(hipMalloc((void**)&dws, (size_t)splitk * P * Q * 4 + 1024)); CK(hipMalloc((void**)&dcnt, 4096 * 4)); CK(hipMemset(dcnt, 0, 4096 * 4));
+    CK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dres, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
+    IGemmArgs a = {};
+    a.src0 = dx; a.C0 = C; a.ld0 = C; a.Hs = H; a.Ws = W; a.Ho = H; a.Wo = W; a.P = P; a.ksize = 3; a.stride = 1; a.pad = 1;
+    a.W = dw; a.Q = Q; a.K = K; a.bias = db; a.act = LADI_ACT_NONE; a.out_scale = 1.f; a.out = dout; a.ldo = Q; a.splitk = splitk;
+    a.res0 = dres; a.ldr0 = Q;
+    if (splitk > 1) { a.sk_ws = dws; a.sk_cnt = dcnt; }
+    hipStream_t st; CK(hipStreamCreate(&st));
+    auto launch = [&]() { return launch_halo<HS_TQ, HS_TP, HS_NXB, HS_NSTW, HS_WPN, HS_WMAX>(a, splitk > 1 ? splitk : 1, st); };
+    for (int i = 0; i < 3; ++i) if (int rc = launch()) { printf("launch failed %d\n", rc); return 1; }
+    CK(hipStreamSynchronize(st));
+    std::vector<h16> o1((size_t)P * Q), o2((size_t)P * Q);
+    CK(hipMemcpy(o1.data(), dout, o1.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemset(dout, 0, (size_t)P * Q * 2));
+    launch(); CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(o2.data(), dout, o2.size() * 2, hipMemcpyDeviceToHost));
+    const bool same = memcmp(o1.data(), o2.data(), o1.size() * 2) == 0;
+    // CPU reference on sampled outputs (every sample's corners, edges and a pseudo-random interior set)
+    double num = 0, den = 0; float worst = 0; int checked = 0;
+    unsigned s2 = 777u;
+    for (int it = 0; it < 600; ++it) {
+        s2 = s2 * 1664525u + 1013904223u;
+        int p = (int)((s2 >> 8) % (unsigned)P), q = (int)((s2 >> 3) % (unsigned)Q);
+        if (it < 64) { const int nn = it / 4, cy = (it & 1) ? H - 1 : 0, cx = (it & 2) ? W - 1 : 0; p = (nn * H + cy) * W + cx; }
+        const int nn = p / (H * W), rem = p % (H * W), oy = rem / W, ox = rem % W;
+        double acc = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const h16* xp = &hx[((size_t)(nn * H + iy) * W + ix) * C];
+            const h16* wp = &hw[(size_t)q * K + (size_t)t * C];
+            for (int c = 0; c < C; ++c) acc += (double)(float)xp[c] * (double)(float)wp[c];
+        }
+        const float pre = (float)(h16)((float)acc + (float)hb[q]);
+        const float ref = pre + (float)hr[(size_t)p * Q + q];
+        const float got = (float)o1[(size_t)p * Q + q];
+        num += (double)(got - ref) * (got - ref); den += (double)ref * ref;
+        worst = fmaxf(worst, fabsf(got - ref)); ++checked;
+    }
+    const double rel = sqrt(num / (den + 1e-30));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int iters = 30;
+    float best = 1e9f, sum = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) launch();
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = fminf(best, ms); sum += ms;
+    }
+    const double us = best * 1000.0 / iters, gf = 2.0 * P * Q * (double)K / 1e9;
+    printf("SCHED %2d <%d,%d,%d,%d,%d,%d> %dx%d %d->%d sk%d  best %7.1f us (mean %7.1f)  %6.0f TFLOP/s  rel-L2 %.2e  max|d| %.3g  repeat-bit-equal %s  %s\n",
+           LADI_HALO_SCHED, HS_TQ, HS_TP, HS_NXB, HS_NSTW, HS_WPN, HS_WMAX, H, W, C, Q, splitk, us, sum / 3 * 1000.0 / iters, gf / us * 1e3, rel, worst,
+           same ? "yes" : "NO", (rel < 2e-3 && same) ? "OK" : "FAIL");
+    return (rel < 2e-3 && same) ? 0 : 2;
+}
