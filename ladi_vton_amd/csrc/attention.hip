@@ -157,26 +157,17 @@ __global__ __launch_bounds__(256, WPS) void flash_attn64_kernel(const AttnArgs a
         auto process = [&](auto SubC) __attribute__((always_inline)) {
             constexpr int sub = decltype(SubC)::value;
             const int key0 = t * KV_STAGE + sub * 64;
+            // (Round 6: hipcc schedules the two products below as [fragment read -> s_waitcnt lgkmcnt(0) -> QB MFMAs] x 8.  Rotating three fragment
+            // registers with the order pinned by sched_barrier -- reads two fragments ahead, lgkmcnt(2) -- was built and measured on one box against
+            // this form: 3 072-token self-attention 0.252 / 0.249 ms (this form) vs 0.247 / 0.256 ms, i.e. no difference for 20 more registers (226 ->
+            // 246): the partner wave on the SIMD already covers the round trips.  profiles/r06_ab_vs_r05.txt; tools/experiments/attn_pipelined_reads.patch)
             // ---- S^T = K Q^T - m_run : two 32-key blocks x QB query blocks (one K fragment read per QB MFMAs).  The running
             // reference m_run of the lane's query is folded into the accumulator init, so the exponent argument comes straight
             // out of the MFMA (no per-element subtract); the very first sub-tile starts from 0 and sets the reference.
             const bool first = key0 == 0;
             f32x16 s_acc[QB][2];
-            // Round 6: the fragment reads run PD - 1 reads ahead of their MFMAs, with the order PINNED (sched_barrier).  hipcc's own schedule of
-            // the plain loop was [ds_read_b128 -> s_waitcnt lgkmcnt(0) -> QB MFMAs] x 8 -- every K fragment's LDS round trip exposed between two
-            // MFMA pairs (ISA: tools/r06/README.md) -- and the same for the transposed V reads of the PV product below.
-            constexpr int PD = QB == 2 ? 3 : 2;            // fragment registers in rotation (the one-query-block form has 10 spare registers, not 16)
-            h16x8 kfr[PD];
-            auto kread = [&](auto Ic) {
-                constexpr int idx = decltype(Ic)::value, kb = idx >> 2, ks = idx & 3;
-                const int r = sub * 64 + kb * 32 + l31;
-                kfr[idx % PD] = *reinterpret_cast<const h16x8*>(sK + kswz(r, ks * 2 + hh));
-            };
-            static_for<0, PD - 1>([&](auto Ic) { kread(Ic); });
-            __builtin_amdgcn_sched_barrier(0);
-            // the reference enters through one extra MFMA k-step per accumulator; issued first, these four MFMAs cover the first reads' latency
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     f32x16 z;
@@ -184,16 +175,15 @@ __global__ __launch_bounds__(256, WPS) void flash_attn64_kernel(const AttnArgs a
                     for (int r = 0; r < 16; ++r) z[r] = 0.f;
                     s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones_f, mneg[qb], z, 0, 0, 0);   // = -m_run of the lane's query, exactly
                 }
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, 8>([&](auto Ic) {
-                constexpr int idx = decltype(Ic)::value, kb = idx >> 2, ks = idx & 3;
-                if constexpr (idx + PD - 1 < 8) kread(IntC<idx + PD - 1>{});
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr[idx % PD], qf[qb][ks], s_acc[qb][kb], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            });
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int r = sub * 64 + kb * 32 + l31;
+                    const h16x8 kf = *reinterpret_cast<const h16x8*>(sK + kswz(r, ks * 2 + hh));
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        s_acc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], s_acc[qb][kb], 0, 0, 0);
+                }
+            }
             // ---- online softmax (lane-local query); masking only on the ragged last sub-tile
             h16x8 pf[QB][2][2];
 #pragma unroll
@@ -251,30 +241,25 @@ __global__ __launch_bounds__(256, WPS) void flash_attn64_kernel(const AttnArgs a
                     }
                 l_run[qb] += psum;
             }
-            // ---- O^T += V^T P^T (one V^T fragment read per QB MFMAs), reads PD - 1 fragments ahead like the K side
-            h16x8 vfr[PD];
-            auto vread = [&](auto Ic) {
-                constexpr int idx = decltype(Ic)::value, kb = idx >> 2, k2 = (idx >> 1) & 1, d = idx & 1;
-                const int kbase = sub * 64 + kb * 32 + k2 * 16;   // + 4 hh + (k >> 2) sits in tr_off
-                const h16* vb = sV + kbase * 64 + tr_off[d];
-                const f16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_t)vb);
-                const f16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_t)(vb + 8 * 64));
-                h16x8 vf;
-                vf[0] = (h16)lo[0]; vf[1] = (h16)lo[1]; vf[2] = (h16)lo[2]; vf[3] = (h16)lo[3];
-                vf[4] = (h16)hi[0]; vf[5] = (h16)hi[1]; vf[6] = (h16)hi[2]; vf[7] = (h16)hi[3];
-                vfr[idx % PD] = vf;
-            };
-            static_for<0, PD - 1>([&](auto Ic) { vread(Ic); });
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, 8>([&](auto Ic) {
-                constexpr int idx = decltype(Ic)::value, kb = idx >> 2, k2 = (idx >> 1) & 1, d = idx & 1;
-                if constexpr (idx + PD - 1 < 8) vread(IntC<idx + PD - 1>{});
-                __builtin_amdgcn_sched_barrier(0);
+            // ---- O^T += V^T P^T (one V^T fragment read per QB MFMAs)
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    o_acc[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfr[idx % PD], pf[qb][kb][k2], o_acc[qb][d], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            });
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int kbase = sub * 64 + kb * 32 + k2 * 16;   // + 4 hh + (k >> 2) sits in tr_off
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const h16* vb = sV + kbase * 64 + tr_off[d];
+                        const f16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_t)vb);
+                        const f16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_t)(vb + 8 * 64));
+                        h16x8 vf;
+                        vf[0] = (h16)lo[0]; vf[1] = (h16)lo[1]; vf[2] = (h16)lo[2]; vf[3] = (h16)lo[3];
+                        vf[4] = (h16)hi[0]; vf[5] = (h16)hi[1]; vf[6] = (h16)hi[2]; vf[7] = (h16)hi[3];
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+                            o_acc[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kb][k2], o_acc[qb][d], 0, 0, 0);
+                    }
+                }
         };
         process(SubIdx<0>{});
         if constexpr (KV_STAGE == 128) { if (t * KV_STAGE + 64 < a.Nk) process(SubIdx<1>{}); }

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void gn_reduce_rows_kernel(const float* __rest
                 for (int l = 1; l < lanes; ++l) { const float4 u = red[l * q + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
                 reinterpret_cast<float4*>(out)[((size_t)n * r2 + b) * q + tid] = t;
             }
-        } else if (qi < q) {
+        } else if (rl < lanes && qi < q) {              // one row lane: threads beyond the row's q pieces (tid >= q) hold nothing
             reinterpret_cast<float4*>(out)[((size_t)n * r2 + b) * q + qi] = acc;
         }
     }
@@ -557,7 +557,13 @@ int ladi_launch_layernorm(const h16* x, int ldx, const h16* gamma, const h16* be
                           int ldo, hipStream_t st) {
     if ((C & 7) || C > 4096 || (ldx & 7) || (ldo & 7)) return -1;
     const int octs = C >> 3;
-    if (octs <= 64) hipLaunchKernelGGL((layernorm_kernel<4, 1>), dim3((rows + 15) / 16), dim3(256), 0, st, x, ldx, gamma, beta, eps, rows, C, out, ldo);
+    // few rows (the 16x12 / 8x6 levels: 3 072 / 768 tokens at batch 8): one row per wave -- four rows per wave would leave most SIMDs without a wave and
+    // the launch is latency, not bandwidth (7.8 us for 7.9 MB in round 5); LADI_LN_R4=1 restores the four-row form everywhere (A/B)
+    static const bool r4_always = [] { const char* e = getenv("LADI_LN_R4"); return e && e[0] == '1'; }();
+    const bool few = rows <= 4096 && !r4_always;
+    if (octs <= 64 && few) hipLaunchKernelGGL((layernorm_kernel<1, 1>), dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, gamma, beta, eps, rows, C, out, ldo);
+    else if (octs <= 64) hipLaunchKernelGGL((layernorm_kernel<4, 1>), dim3((rows + 15) / 16), dim3(256), 0, st, x, ldx, gamma, beta, eps, rows, C, out, ldo);
+    else if (octs <= 192 && few) hipLaunchKernelGGL((layernorm_kernel<1, 3>), dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, gamma, beta, eps, rows, C, out, ldo);
     else if (octs <= 192) hipLaunchKernelGGL((layernorm_kernel<4, 3>), dim3((rows + 15) / 16), dim3(256), 0, st, x, ldx, gamma, beta, eps, rows, C, out, ldo);
     else hipLaunchKernelGGL((layernorm_kernel<1, 8>), dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, gamma, beta, eps, rows, C, out, ldo);
     return hipGetLastError() == hipSuccess ? 0 : -11;

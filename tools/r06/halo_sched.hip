@@ -24,9 +24,15 @@
 #define HS_WPN 2
 #define HS_WMAX 24
 #endif
+#ifndef HS_ONE
+#define HS_ONE 0
+#endif
+#ifndef HS_G2D
+#define HS_G2D 0
+#endif
 
 int main(int argc, char** argv) {
-    const int n = 16, H = argc > 1 ? atoi(argv[1]) : 32, W = argc > 2 ? atoi(argv[2]) : 24, C = argc > 3 ? atoi(argv[3]) : 640, Q = argc > 4 ? atoi(argv[4]) : 640;
+    const int n = argc > 6 ? atoi(argv[6]) : 16, H = argc > 1 ? atoi(argv[1]) : 32, W = argc > 2 ? atoi(argv[2]) : 24, C = argc > 3 ? atoi(argv[3]) : 640, Q = argc > 4 ? atoi(argv[4]) : 640;
     const int splitk = argc > 5 ? atoi(argv[5]) : 1;
     const int P = n * H * W, K = 9 * C;
     std::vector<h16> hx((size_t)P * C), hw((size_t)Q * K), hb(Q), hr((size_t)P * Q);
@@ -48,7 +54,7 @@ int main(int argc, char** argv) {
     a.res0 = dres; a.ldr0 = Q;
     if (splitk > 1) { a.sk_ws = dws; a.sk_cnt = dcnt; }
     hipStream_t st; CK(hipStreamCreate(&st));
-    auto launch = [&]() { return launch_halo<HS_TQ, HS_TP, HS_NXB, HS_NSTW, HS_WPN, HS_WMAX>(a, splitk > 1 ? splitk : 1, st); };
+    auto launch = [&]() { return launch_halo<HS_TQ, HS_TP, HS_NXB, HS_NSTW, HS_WPN, HS_WMAX, HS_ONE, HS_G2D>(a, splitk > 1 ? splitk : 1, st); };
     for (int i = 0; i < 3; ++i) if (int rc = launch()) { printf("launch failed %d\n", rc); return 1; }
     CK(hipStreamSynchronize(st));
     std::vector<h16> o1((size_t)P * Q), o2((size_t)P * Q);
@@ -63,7 +69,7 @@ int main(int argc, char** argv) {
     for (int it = 0; it < 600; ++it) {
         s2 = s2 * 1664525u + 1013904223u;
         int p = (int)((s2 >> 8) % (unsigned)P), q = (int)((s2 >> 3) % (unsigned)Q);
-        if (it < 64) { const int nn = it / 4, cy = (it & 1) ? H - 1 : 0, cx = (it & 2) ? W - 1 : 0; p = (nn * H + cy) * W + cx; }
+        if (it < 64) { const int nn = (it / 4) % n, cy = (it & 1) ? H - 1 : 0, cx = (it & 2) ? W - 1 : 0; p = (nn * H + cy) * W + cx; }
         const int nn = p / (H * W), rem = p % (H * W), oy = rem / W, ox = rem % W;
         double acc = 0;
         for (int t = 0; t < 9; ++t) {
@@ -91,8 +97,8 @@ int main(int argc, char** argv) {
         best = fminf(best, ms); sum += ms;
     }
     const double us = best * 1000.0 / iters, gf = 2.0 * P * Q * (double)K / 1e9;
-    printf("SCHED %2d <%d,%d,%d,%d,%d,%d> %dx%d %d->%d sk%d  best %7.1f us (mean %7.1f)  %6.0f TFLOP/s  rel-L2 %.2e  max|d| %.3g  repeat-bit-equal %s  %s\n",
-           LADI_HALO_SCHED, HS_TQ, HS_TP, HS_NXB, HS_NSTW, HS_WPN, HS_WMAX, H, W, C, Q, splitk, us, sum / 3 * 1000.0 / iters, gf / us * 1e3, rel, worst,
+    printf("SCHED %2d <%d,%d,%d,%d,%d,%d,%d,%d> n%d %dx%d %d->%d sk%d  best %7.1f us (mean %7.1f)  %6.0f TFLOP/s  rel-L2 %.2e  max|d| %.3g  repeat-bit-equal %s  %s\n",
+           LADI_HALO_SCHED, HS_TQ, HS_TP, HS_NXB, HS_NSTW, HS_WPN, HS_WMAX, HS_ONE, HS_G2D, n, H, W, C, Q, splitk, us, sum / 3 * 1000.0 / iters, gf / us * 1e3, rel, worst,
            same ? "yes" : "NO", (rel < 2e-3 && same) ? "OK" : "FAIL");
     return (rel < 2e-3 && same) ? 0 : 2;
 }
