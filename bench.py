@@ -187,7 +187,7 @@ def traffic_measured(symbol, extra_args):
             "launches": vals["FETCH_SIZE"][1], "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH doubled)"}, None
 
 
-PROFILE_ROUND = "r05"      # the committed rocprofv3 summaries this line may cite (profiles/<round>_*), digest-checked
+PROFILE_ROUND = "r06"      # the committed rocprofv3 summaries this line may cite (profiles/<round>_*), digest-checked
 
 
 def _pmc_file(prefix, tag):
@@ -223,7 +223,7 @@ def _stats_file(prefix):
     return out
 
 
-HBM_KERNELS = ("gn_norm_kernel", "gn_apply_kernel", "gn_finalize_kernel", "gn_partial_kernel", "splitk_reduce_kernel", "layernorm_kernel", "sched_step_kernel",
+HBM_KERNELS = ("gn_norm_kernel", "gn_reduce_rows_kernel", "gn_apply_kernel", "gn_finalize_kernel", "gn_partial_kernel", "splitk_reduce_kernel", "layernorm_kernel", "sched_step_kernel",
                "image_post_kernel", "assemble_static_kernel")
 
 
@@ -273,11 +273,10 @@ def traffic_committed(symbol):
         m = re.match(r"# lib_digest=(\w+)", lines[0]) if lines else None
         if not m or m.group(1) != lib_digest():
             return None, "committed PMC passes are stale (taken with another library build); re-run with --measure-traffic"
-        # rocprofv3 prints EVERY template argument of a kernel, the tile table's symbol only the leading ones ("igemm_halo_kernel<2, 2, 1, 3, 2, 24>"
-        # is "...<2, 2, 1, 3, 2, 24, 0, 0>" in a trace since the halo kernel grew defaulted arguments): match the argument list as a prefix
-        stem = symbol[:-1] if symbol.endswith(">") else symbol
+        # the tile table names a kernel exactly as rocprofv3 prints it -- every template argument, defaulted ones included (round 6; the prefix
+        # match of round 5 could hand a ring-halo symbol the 2-D blocked form's bytes when both were in one trace: ADVICE r05)
         for line in lines[1:]:
-            if (stem + ">") in line or (stem + ",") in line:
+            if symbol in line:
                 vals[tag] = float(line.split()[-2]) * 1024.0   # avg KiB per dispatch -> bytes
                 break
     if len(vals) != 2:

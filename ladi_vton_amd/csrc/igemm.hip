@@ -290,18 +290,18 @@ std::string cfg_symbol(int c) {
         case 56: return "igemm8_kernel<2, 1, 0>";
         case 57: return "igemm8_kernel<5, 1, 0>";
         case 58: return "igemm8_kernel<3, 2, 0>";
-        case 74: return "igemm_halo_kernel<2, 2, 2, 3, 4, 48>";
-        case 75: return "igemm_halo_kernel<4, 2, 1, 3, 4, 48>";
-        case 76: return "igemm_halo_kernel<5, 2, 1, 2, 4, 48>";
-        case 77: return "igemm_halo_kernel<2, 1, 2, 4, 4, 48>";
-        case 78: return "igemm_halo_kernel<4, 1, 1, 3, 4, 48>";
-        case 84: return "igemm_halo_kernel<2, 2, 1, 2, 2, 48>";
-        case 85: return "igemm_halo_kernel<2, 3, 1, 2, 2, 48>";
-        case 88: return "igemm_halo_kernel<2, 2, 1, 3, 2, 24>";
-        case 89: return "igemm_halo_kernel<2, 3, 1, 3, 2, 24>";
-        case 92: return "igemm_halo_kernel<5, 1, 1, 2, 6, 48>";
-        case 96: return "igemm_halo_kernel<5, 3, 1, 2, 2, 48, 1>";
-        case 97: return "igemm_halo_kernel<2, 4, 1, 2, 2, 24>";
+        case 74: return "igemm_halo_kernel<2, 2, 2, 3, 4, 48, 0, 0>";
+        case 75: return "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 0>";
+        case 76: return "igemm_halo_kernel<5, 2, 1, 2, 4, 48, 0, 0>";
+        case 77: return "igemm_halo_kernel<2, 1, 2, 4, 4, 48, 0, 0>";
+        case 78: return "igemm_halo_kernel<4, 1, 1, 3, 4, 48, 0, 0>";
+        case 84: return "igemm_halo_kernel<2, 2, 1, 2, 2, 48, 0, 0>";
+        case 85: return "igemm_halo_kernel<2, 3, 1, 2, 2, 48, 0, 0>";
+        case 88: return "igemm_halo_kernel<2, 2, 1, 3, 2, 24, 0, 0>";
+        case 89: return "igemm_halo_kernel<2, 3, 1, 3, 2, 24, 0, 0>";
+        case 92: return "igemm_halo_kernel<5, 1, 1, 2, 6, 48, 0, 0>";
+        case 96: return "igemm_halo_kernel<5, 3, 1, 2, 2, 48, 1, 0>";
+        case 97: return "igemm_halo_kernel<2, 4, 1, 2, 2, 24, 0, 0>";
         case 100: return "igemm_halo_kernel<2, 2, 1, 3, 4, 48, 0, 1>";
         case 101: return "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 1>";
         case 102: return "igemm_halo_kernel<5, 2, 1, 2, 4, 48, 0, 1>";

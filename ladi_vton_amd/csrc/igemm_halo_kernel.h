@@ -21,6 +21,7 @@
 #include "kernels.h"
 #include "igemm_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -97,10 +98,23 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
 
     const int tid = threadIdx.x;
     const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
-    int qt, pt;
+    int qt, pt, z = blockIdx.z;
     {
         const int b = blockIdx.x;
-        if (a.tile_map == 1) {
+        if ((a.tile_map & 15) == 3) {
+            // Round 6 -- WEIGHT-SLICE-major map for the deep, few-pixel levels (8x6 / 16x12: the weights are 4-15x the pixel operand).  A unit =
+            // (channel tile, K slice, group of G pixel tiles); unit u runs on XCD u % 8 and its G workgroups are consecutive there, so they
+            // start together and the XCD's L2 serves G - 1 of the G reads of every weight tile.  With the plain maps the pixel tiles of one
+            // weight slice land on 4-8 different XCDs and every L2 fetches the slice again: 197 MB of fabric traffic per launch for 34 MB of
+            // operands on the 8x6 convolutions (profiles/r05_pmc_fetch_size.txt), at 4.3 TB/s the limiter of that kernel.  grid.z = 1.
+            const int G = a.tile_map >> 4, S = a.splitk > 1 ? a.splitk : 1, npg = (np + G - 1) / G;
+            const int xcd = b & 7, loc = b >> 3, ui = loc / G, pi = loc - ui * G;
+            const int u = ui * 8 + xcd;                      // unit index = (qt * S + z) * npg + pg
+            if (u >= nq * S * npg) return;
+            const int pg = u % npg, qz = u / npg;
+            pt = pg * G + pi; qt = qz / S; z = qz - qt * S;
+            if (pt >= np) return;
+        } else if (a.tile_map == 1) {
             const int npx = (np + 7) >> 3, xcd = b & 7, loc = b >> 3;
             pt = xcd * npx + loc / nq; qt = loc % nq;
             if (pt >= np) return;
@@ -120,7 +134,6 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
         g_y0 = ty * TH; g_x0 = (t - ty * txn) * 32;
     }
     const int p0 = G2D ? (g_n * a.Hs + g_y0) * a.Ws + g_x0 : pt * BP;
-    const int z = blockIdx.z;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int wq = wave / WP, wp = wave % WP;
@@ -339,7 +352,25 @@ int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
     a.tile_map = 0;
     if (np >= 16) { a.tile_map = 1; blocks = 8 * ((np + 7) / 8) * nq; }
     else if (nq >= 16) { a.tile_map = 2; blocks = 8 * ((nq + 7) / 8) * np; }
-    dim3 grid((unsigned)blocks, 1, (unsigned)batch);
+    // weight-slice-major map (see the kernel): when the weights outweigh the pixel operand at least 3:1.  G = half of the pixel tiles of a
+    // slice (the 16x12 level: 24 tiles -> 40 units of 12, 60 workgroups per XCD).  Measured (profiles/r06_halo_map3.txt): fabric traffic of the
+    // 16x12 convolution 1280 -> 1280 283 + 38 MB -> 112 + 38 MB per launch, time unchanged (2560 -> 1280: -4 %); on the 8x6 level (G = all 6
+    // tiles) 148 + 17 MB -> 50 + 17 MB and the launch gets 5 % SLOWER (six workgroups of an XCD asking for the same weight lines at the same
+    // moment) -- that kernel was never bandwidth-bound (VERDICT r05 read its 4.3 TB/s as the limiter), so the map is offered from 13 pixel
+    // tiles up only; LADI_HALO_MAP3=0 keeps the round-5 maps everywhere, =2 forces it for every eligible launch (A/B)
+    int gz = batch;
+    {
+        static const int mode = [] { const char* e = getenv("LADI_HALO_MAP3"); return e ? atoi(e) : 1; }();
+        const bool off = mode == 0 || (mode != 2 && np <= 12);
+        const size_t wbytes = (size_t)a.Q * a.K * 2, xbytes = (size_t)a.P * (a.C0 + a.C1) * 2;
+        const int S = a.splitk > 1 ? a.splitk : 1;
+        if (!off && !G2D && (batch == 1 || a.splitk > 1) && wbytes >= 3 * xbytes && np <= 32 && np >= 2) {
+            const int G = np <= 12 ? np : (np + 1) / 2;
+            const int units = nq * S * ((np + G - 1) / G);
+            if (G <= 255 && units >= 8) { a.tile_map = 3 | (G << 4); blocks = 8 * ((units + 7) / 8) * G; gz = 1; }
+        }
+    }
+    dim3 grid((unsigned)blocks, 1, (unsigned)gz);
     hipLaunchKernelGGL(kfn, grid, dim3(128 * WPN), SMEM, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -11;
 }

@@ -19,7 +19,7 @@ def lib():
 
 
 def pytest_sessionstart(session):
-    """a GPU session starts its parity record from scratch (tests/util.py record_parity): the committed profiles/r05_parity.json is one run"""
+    """a GPU session starts its parity record from scratch (tests/util.py record_parity): the committed profiles/r06_parity.json is one run"""
     import time
     os.environ["LADI_PYTEST_SESSION"] = time.strftime("%Y%m%dT%H%M%S")
     markexpr = getattr(session.config.option, "markexpr", "") or ""

@@ -292,8 +292,11 @@ def test_igemm_tile_table_names_every_configuration(lib):
     assert all(re.fullmatch(r"(igemm_kernel|igemm8_kernel|igemm_lc_kernel|igemm_halo_kernel)<[0-9a-z, ]+>|linear_xs_kernel", s) for s in names), names
     fam = {s.split("<")[0] for s in names}
     assert fam == {"igemm_kernel", "igemm8_kernel", "igemm_lc_kernel", "igemm_halo_kernel", "linear_xs_kernel"}, fam
-    assert names[84 - 1] == "igemm_halo_kernel<2, 2, 1, 2, 2, 48>"    # the dominant symbol of the round-3 forward (profiles/r03_bench_default.json)
-    assert names[92 - 1] == "igemm_halo_kernel<5, 1, 1, 2, 6, 48>"    # round 4: the 12-wave 320x192 form (256 workgroups on the 64x48 level)
+    assert names[84 - 1] == "igemm_halo_kernel<2, 2, 1, 2, 2, 48, 0, 0>"    # the dominant symbol of the round-3 forward (profiles/r03_bench_default.json)
+    assert names[92 - 1] == "igemm_halo_kernel<5, 1, 1, 2, 6, 48, 0, 0>"    # round 4: the 12-wave 320x192 form (256 workgroups on the 64x48 level)
+    # round 6: halo symbols carry EVERY template argument, as rocprofv3 prints them, so that a ring-halo form and the 2-D blocked form of the same
+    # leading arguments (cfg 75 / 101) can never be taken for each other when bench.py looks a symbol up in a committed trace
+    assert names[75 - 1] == "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 0>" and names[101 - 1] == "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 1>"
     assert not lib.ladi_igemm_cfg_symbol_name(0) and not lib.ladi_igemm_cfg_symbol_name(n + 1)   # out of range: empty, not a crash
 
 
@@ -828,16 +831,18 @@ def test_bench_hbm_kernels_reads_the_committed_profiles(monkeypatch):
     duration of the committed kernel trace, accepted only for the library digest stamped into the files' first line"""
     import bench
     path = os.path.join(ROOT, "profiles", "%s_pmc_fetch_size.txt" % bench.PROFILE_ROUND)
+    if not os.path.exists(path):
+        pytest.skip("the PMC passes of %s are not committed yet" % bench.PROFILE_ROUND)
     dig = re.match(r"# lib_digest=(\w+)", open(path).readline()).group(1)
     monkeypatch.setattr(bench, "lib_digest", lambda: dig)
     h = bench.hbm_kernels()
     ga = h["unet_forward"]["gn_norm_kernel"]          # round 5: the UNet's GroupNorms are one-pass launches (finalize folded into apply)
     assert 500.0 < ga["GBps"] < 8000.0 and abs(ga["GBps"] - ga["MB_per_launch"] * 1e3 / ga["avg_us"]) < 1.0, ga
-    assert any("gn_apply" in k for k in h["vae_stages"]) and "source" in h
-    t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24>")
+    assert any("gn_" in k for k in h["vae_stages"]) and "source" in h      # (round 6: the VAE's GroupNorms are gn_reduce_rows + gn_norm launches)
+    t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24, 0, 0>")
     assert why is None and abs(t["bytes_per_launch"] - (t["fetch_bytes_x2"] + t["write_bytes"])) <= 2 and t["bytes_per_launch"] > 10_000_000   # each term is rounded on its own
     monkeypatch.setattr(bench, "lib_digest", lambda: "another-build")
-    t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24>")
+    t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24, 0, 0>")
     assert t is None and "stale" in why
     assert "note" in bench.hbm_kernels()["unet_forward"]
 
@@ -861,16 +866,16 @@ PARITY_KEYS_CITED = ["unet_forward_full_64x48_n16_vs_oracle", "config2_chain_B2_
 
 
 def test_committed_parity_record_is_one_run_and_holds_every_cited_key():
-    """profiles/r05_parity.json is ONE full `pytest -m gpu` run on one binary (tests/util.py record_parity stamps the library digest and the
+    """profiles/r06_parity.json is ONE full `pytest -m gpu` run on one binary (tests/util.py record_parity stamps the library digest and the
     session id; tests/conftest.py starts every GPU session from an empty record) and holds every key the documents cite -- explicitly listed
     above, plus every `..._vs_oracle` key a document names in back-ticks (the round-4 file was a 3-key fragment that lacked the
     key BASELINE.md quoted)."""
     import json
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "profiles", "r05_parity.json")
+    path = os.path.join(root, "profiles", "r06_parity.json")
     if not os.path.exists(path):
-        pytest.skip("no round-5 parity record committed yet")
+        pytest.skip("no round-6 parity record committed yet")
     blob = json.load(open(path))
     assert re.fullmatch(r"[0-9a-f]{64}", blob.get("_library_digest", "")), "the record names the library it was taken on"
     assert blob.get("_session"), "the record names its pytest session"

@@ -110,7 +110,7 @@ def cpu_quota_threads():
     return n
 
 
-PARITY_NAME = "parity_r05.json"
+PARITY_NAME = "parity_r06.json"
 
 
 def library_digest():
@@ -126,9 +126,9 @@ def parity_path():
 
 
 def record_parity(key, value, name=None):
-    """Measured parity values of the GPU suite -> gpurun_out/parity_r05.json (the only directory that comes back from the GPU box), stamped
+    """Measured parity values of the GPU suite -> gpurun_out/parity_r06.json (the only directory that comes back from the GPU box), stamped
     with the library digest and the pytest session id: tests/conftest.py removes the file at the start of every GPU session, so the record
-    is ONE run of ONE binary, never a stitch.  `python tools/commit_parity.py` copies it to profiles/r05_parity.json after
+    is ONE run of ONE binary, never a stitch.  `python tools/commit_parity.py` copies it to profiles/r06_parity.json after
     checking the digest against the sources; tests/test_cpu.py checks that every key the documents cite is in the committed file."""
     import json
     import os

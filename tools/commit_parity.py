@@ -1,5 +1,5 @@
-"""Copy the parity record of the last full `pytest -m gpu` run (gpurun_out/parity_r05.json, written by tests/util.py record_parity) to
-profiles/r05_parity.json -- only if it was taken on the binary the current sources build (library digest) and holds every key the
+"""Copy the parity record of the last full `pytest -m gpu` run (gpurun_out/parity_r06.json, written by tests/util.py record_parity) to
+profiles/r06_parity.json -- only if it was taken on the binary the current sources build (library digest) and holds every key the
 documents cite (tests/test_cpu.py PARITY_KEYS_CITED).  python tools/commit_parity.py [--allow-stale-digest]"""
 import json
 import os
@@ -21,8 +21,8 @@ def main():
     missing = [k for k in PARITY_KEYS_CITED if k not in blob]
     if missing:
         sys.exit("parity record lacks cited keys (partial run?): %s" % missing)
-    shutil.copyfile(src, os.path.join(ROOT, "profiles", "r05_parity.json"))
-    print("profiles/r05_parity.json <- %d keys, library %s" % (len(blob), dig[:8]))
+    shutil.copyfile(src, os.path.join(ROOT, "profiles", "r06_parity.json"))
+    print("profiles/r06_parity.json <- %d keys, library %s" % (len(blob), dig[:8]))
 
 
 if __name__ == "__main__":
