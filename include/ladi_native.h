@@ -246,6 +246,12 @@ int ladi_tryon_run_u8(ladi_tryon* t, const ladi_tryon_inputs* in, unsigned char*
 int ladi_tryon_set_trace(ladi_tryon* t, float* eps_trace_dev, float* latents_trace_dev, int cap_evals);
 /* stage times (ms) of the last run: [0] preprocess + VAE encodes + EMASC, [1] denoising loop, [2] decode. Sync first. */
 int ladi_tryon_stage_ms(ladi_tryon* t, float* out3);
+/* fp16-range guard of the decode, examined WITHOUT a host round trip inside ladi_tryon_run (round 6): a run decodes once and queues the guard's flag
+ * behind its last kernel.  Returns 0 if the last run's decode stayed inside the fp16 range (or nothing is pending), 1 if it did not -- that run's
+ * images are invalid; with ladi_vae_set_range_shift(-1) (automatic, the default) the shift has been raised (0 -> 4 -> 8) and re-submitting the
+ * batch gives the result -- and < 0 on error.  Waits for the queued flag copy (i.e. for the run to finish).  A caller that never asks is told by
+ * the NEXT ladi_tryon_run, which then fails with -101 instead of running. */
+int ladi_tryon_poll_overflow(ladi_tryon* t);
 /* sample-group lanes of the denoising loop: the UNet forward of the 2B (CFG) or B samples runs as `lanes` independent forwards on as
  * many HIP streams inside one hipGraph (csrc/runtime.h UNetLanes).  0 = default (environment LADI_UNET_LANES, else 1); a count that
  * does not divide the sample count falls back to the default rule.  Results do not depend on it beyond fp16 rounding of other tile

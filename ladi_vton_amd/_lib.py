@@ -129,6 +129,7 @@ SIGNATURES = {
     "ladi_tryon_run": (c_int, [_P, POINTER(TryOnInputs), _P, _P, _P]),
     "ladi_tryon_run_u8": (c_int, [_P, POINTER(TryOnInputs), _P, _P, _P]),
     "ladi_tryon_stage_ms": (c_int, [_P, POINTER(c_float)]),
+    "ladi_tryon_poll_overflow": (c_int, [_P]),
     "ladi_tryon_set_trace": (c_int, [_P, _P, _P, c_int]),
     "ladi_tryon_set_lanes": (c_int, [_P, c_int]),
     "ladi_tryon_lanes": (c_int, [_P]),

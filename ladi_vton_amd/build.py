@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libladi_native.so")
-SOURCES = ["igemm.hip"] + ["igemm_inst_%s.hip" % g for g in "abcdefghi"] + ["igemm8.hip", "igemm_lc.hip", "igemm_halo.hip"] + ["igemm_halo_inst_%s.hip" % g for g in "abcdefgh"] + ["linear_xs.hip", "xf_fused.hip", "norm.hip", "attention.hip", "elementwise.hip", "f32path.hip", "runtime_core.cpp", "runtime_f32.cpp", "runtime_unet.cpp",
+SOURCES = ["igemm.hip"] + ["igemm_inst_%s.hip" % g for g in "abcdefghi"] + ["igemm8.hip", "igemm_lc.hip", "igemm_halo.hip"] + ["igemm_halo_inst_%s.hip" % g for g in "abcdefghij"] + ["linear_xs.hip", "xf_fused.hip", "norm.hip", "attention.hip", "elementwise.hip", "f32path.hip", "runtime_core.cpp", "runtime_f32.cpp", "runtime_unet.cpp",
            "runtime_vae.cpp", "runtime_text.cpp", "runtime_vision.cpp", "runtime_refine.cpp", "runtime_tps.cpp", "runtime_tryon.cpp", "capi.cpp"]
 HEADERS = ["common.h", "kernels.h", "igemm_common.h", "igemm_kernel.h", "igemm_halo_kernel.h", "igemm_tiles.h", "runtime.h", os.path.join("..", "..", "include", "ladi_native.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function"]

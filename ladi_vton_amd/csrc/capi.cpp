@@ -562,6 +562,10 @@ int ladi_tryon_run_u8(ladi_tryon* t, const ladi_tryon_inputs* in, unsigned char*
     return tryon_run_any(t, in, images, 1, latents, stream);
 }
 int ladi_tryon_stage_ms(ladi_tryon* t, float* out3) { return t ? t->t.stage_ms(out3) : -1; }
+int ladi_tryon_poll_overflow(ladi_tryon* t) {
+    if (!t || !t->t.vae) { set_error("ladi_tryon_poll_overflow: null handle"); return -1; }
+    return guarded("ladi_tryon_poll_overflow", [&]() { return t->t.vae->poll_overflow(); });
+}
 int ladi_tryon_set_lanes(ladi_tryon* t, int lanes) {
     if (!t || lanes < 0 || lanes > UNetLanes::MAXG) { set_error("ladi_tryon_set_lanes: lanes must be in [0, 8]"); return -1; }
     t->t.lanes_override = lanes;

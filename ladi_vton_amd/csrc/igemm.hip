@@ -113,7 +113,7 @@ struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; in
 // tile configurations (0 = choose: measured per shape when autotuning is on, else the cost model below).
 // {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K,
 //  K step, offered to the tuner}
-constexpr int NCFG = 103;
+constexpr int NCFG = 108;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1, 0, false},
     {128, 256, 2, true, 0.80f, 4, 1, 1, 32, true},   // 1: <2,2,2,4> BK32 NST3
@@ -242,6 +242,14 @@ const CfgInfo kCfg[NCFG + 1] = {
     {256, 256, 1, false, 0.00f, 2, 101, 1, 64, true},  // 101: halo2d 256x256, 8 waves
     {320, 256, 1, false, 0.00f, 2, 102, 1, 64, true},  // 102: halo2d 320x256, 8 waves
     {128, 128, 2, false, 0.00f, 2, 103, 1, 64, true},  // 103: halo2d 128x128 (4 rows x 32), 4 waves, two workgroups per CU
+    // 104..108 (round 6): halo forms of the FOLDED-UPSAMPLE convolution (igemm_halo_kernel.h UPS: nearest 2x + 3x3 of Upsample2D): the low-resolution
+    // rows a tile touches staged once per channel chunk, taps applied at read time -- the ring kernels gather every tap with per-lane addressing
+    // (64x48 640 -> 640: 382 us, 32x24 1280 -> 1280: 379 us in round 5; here 307 / 304 us, profiles/r06_halo_ups.txt)
+    {128, 192, 2, false, 0.00f, 3, 104, 1, 64, true},  // 104: halo-ups 128x192, 4 waves, two workgroups per CU
+    {320, 192, 1, false, 0.00f, 1, 105, 1, 64, true},  // 105: halo-ups 320x192, 12 waves
+    {128, 128, 2, false, 0.00f, 2, 106, 1, 64, true},  // 106: halo-ups 128x128, 4 waves, two workgroups per CU
+    {128, 192, 2, false, 0.00f, 3, 104, 2, 64, true},  // 107: cfg 104 + split-K 2
+    {128, 128, 2, false, 0.00f, 2, 106, 2, 64, true},  // 108: cfg 106 + split-K 2
 };
 inline bool is_xs(int base) { return base == 23 || base == 93; }
 inline int xs_nst(int base) { return base == 93 ? 2 : 3; }
@@ -277,6 +285,7 @@ bool sk_two_pass_forced() {
 inline bool is_halo(int base) { return (base >= 74 && base <= 78) || base == 84 || base == 85 || base == 88 || base == 89 || base == 92 || base == 96 || base == 97; }
 inline bool is_halo2d(int base) { return base >= 100 && base <= 103; }
 inline int halo2d_th(int base) { return base == 103 ? 4 : 8; }
+inline bool is_halo_ups(int base) { return base >= 104 && base <= 106; }
 
 // rocprofv3's name of the kernel a configuration launches (bench.py groups its per-launch timings by symbol)
 std::string cfg_symbol(int c) {
@@ -290,22 +299,25 @@ std::string cfg_symbol(int c) {
         case 56: return "igemm8_kernel<2, 1, 0>";
         case 57: return "igemm8_kernel<5, 1, 0>";
         case 58: return "igemm8_kernel<3, 2, 0>";
-        case 74: return "igemm_halo_kernel<2, 2, 2, 3, 4, 48, 0, 0>";
-        case 75: return "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 0>";
-        case 76: return "igemm_halo_kernel<5, 2, 1, 2, 4, 48, 0, 0>";
-        case 77: return "igemm_halo_kernel<2, 1, 2, 4, 4, 48, 0, 0>";
-        case 78: return "igemm_halo_kernel<4, 1, 1, 3, 4, 48, 0, 0>";
-        case 84: return "igemm_halo_kernel<2, 2, 1, 2, 2, 48, 0, 0>";
-        case 85: return "igemm_halo_kernel<2, 3, 1, 2, 2, 48, 0, 0>";
-        case 88: return "igemm_halo_kernel<2, 2, 1, 3, 2, 24, 0, 0>";
-        case 89: return "igemm_halo_kernel<2, 3, 1, 3, 2, 24, 0, 0>";
-        case 92: return "igemm_halo_kernel<5, 1, 1, 2, 6, 48, 0, 0>";
-        case 96: return "igemm_halo_kernel<5, 3, 1, 2, 2, 48, 1, 0>";
-        case 97: return "igemm_halo_kernel<2, 4, 1, 2, 2, 24, 0, 0>";
-        case 100: return "igemm_halo_kernel<2, 2, 1, 3, 4, 48, 0, 1>";
-        case 101: return "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 1>";
-        case 102: return "igemm_halo_kernel<5, 2, 1, 2, 4, 48, 0, 1>";
-        case 103: return "igemm_halo_kernel<2, 2, 1, 2, 2, 48, 0, 1>";
+        case 74: return "igemm_halo_kernel<2, 2, 2, 3, 4, 48, 0, 0, 0>";
+        case 75: return "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 0, 0>";
+        case 76: return "igemm_halo_kernel<5, 2, 1, 2, 4, 48, 0, 0, 0>";
+        case 77: return "igemm_halo_kernel<2, 1, 2, 4, 4, 48, 0, 0, 0>";
+        case 78: return "igemm_halo_kernel<4, 1, 1, 3, 4, 48, 0, 0, 0>";
+        case 84: return "igemm_halo_kernel<2, 2, 1, 2, 2, 48, 0, 0, 0>";
+        case 85: return "igemm_halo_kernel<2, 3, 1, 2, 2, 48, 0, 0, 0>";
+        case 88: return "igemm_halo_kernel<2, 2, 1, 3, 2, 24, 0, 0, 0>";
+        case 104: return "igemm_halo_kernel<2, 3, 1, 2, 2, 48, 0, 0, 1>";
+        case 105: return "igemm_halo_kernel<5, 1, 1, 2, 6, 48, 0, 0, 1>";
+        case 106: return "igemm_halo_kernel<2, 2, 1, 2, 2, 48, 0, 0, 1>";
+        case 89: return "igemm_halo_kernel<2, 3, 1, 3, 2, 24, 0, 0, 0>";
+        case 92: return "igemm_halo_kernel<5, 1, 1, 2, 6, 48, 0, 0, 0>";
+        case 96: return "igemm_halo_kernel<5, 3, 1, 2, 2, 48, 1, 0, 0>";
+        case 97: return "igemm_halo_kernel<2, 4, 1, 2, 2, 24, 0, 0, 0>";
+        case 100: return "igemm_halo_kernel<2, 2, 1, 3, 4, 48, 0, 1, 0>";
+        case 101: return "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 1, 0>";
+        case 102: return "igemm_halo_kernel<5, 2, 1, 2, 4, 48, 0, 1, 0>";
+        case 103: return "igemm_halo_kernel<2, 2, 1, 2, 2, 48, 0, 1, 0>";
         case 62: return "igemm_lc_kernel<2, 2, 2, 2, 2, 4>";
         case 63: return "igemm_lc_kernel<2, 2, 2, 2, 2, 5>";
         case 64: return "igemm_lc_kernel<2, 2, 4, 2, 2, 3>";
@@ -351,6 +363,9 @@ int launch_base(int cfg, const IGemmArgs& a, int batch, hipStream_t st) {
         case 101: return ladi_launch_igemm_halo(a, 4, 2, 20, batch, st);
         case 102: return ladi_launch_igemm_halo(a, 5, 2, 20, batch, st);
         case 103: return ladi_launch_igemm_halo(a, 2, 2, 21, batch, st);
+        case 104: return ladi_launch_igemm_halo(a, 2, 3, 30, batch, st);
+        case 105: return ladi_launch_igemm_halo(a, 5, 1, 31, batch, st);
+        case 106: return ladi_launch_igemm_halo(a, 2, 2, 30, batch, st);
         case 62: return ladi_launch_igemm_lc(a, 2, 2, 4, batch, st);
         case 63: return ladi_launch_igemm_lc(a, 2, 2, 5, batch, st);
         case 64: return ladi_launch_igemm_lc(a, 4, 2, 3, batch, st);
@@ -452,6 +467,7 @@ static bool cfg_admissible(const IGemmArgs& a, int batch, int c, bool strict) {
     if (a.gn_ss) return false;                                        // GroupNorm affine of the operand: X-stationary kernel only
     if (a.ln_gamma && !a.ln_scratch) return false;                    // no scratch: only the fused (X-stationary) form
     if (is_lc(ci.base) && (a.ups || batch != 1)) return false;        // loader / consumer kernel: no folded upsample, no batched launches
+    if (is_halo_ups(ci.base) && !ladi_igemm_halo_ups_eligible(a, batch, ci.bp)) return false;   // folded-upsample halo: single source, whole tiles inside a sample
     if (is_halo2d(ci.base) && !ladi_igemm_halo2d_eligible(a, batch, halo2d_th(ci.base))) return false;   // 2-D blocked halo: W % 32 == 0, whole blocks
     if (is_halo(ci.base) && (!ladi_igemm_halo_eligible(a, batch) || ((ci.base == 88 || ci.base == 89 || ci.base == 97) && a.Ws > 24))) return false;   // halo-resident kernel: 3x3 stride-1 convolutions on narrow images
     if (geglu && !ci.geglu_ok) return false;

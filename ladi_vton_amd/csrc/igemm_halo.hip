@@ -22,10 +22,20 @@ int ladi_halo_launch_g256x256(IGemmArgs a, int batch, hipStream_t st);
 int ladi_halo_launch_g320x256(IGemmArgs a, int batch, hipStream_t st);
 int ladi_halo_launch_g128x128_w2(IGemmArgs a, int batch, hipStream_t st);
 int ladi_halo_launch_f128x256_w2n(IGemmArgs a, int batch, hipStream_t st);
+int ladi_halo_launch_u128x192(IGemmArgs a, int batch, hipStream_t st);
+int ladi_halo_launch_u128x128(IGemmArgs a, int batch, hipStream_t st);
+int ladi_halo_launch_u320x192_w6(IGemmArgs a, int batch, hipStream_t st);
 
 bool ladi_igemm_halo_eligible(const IGemmArgs& a, int batch) {
     return a.ksize == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Ws <= HALO_WMAX && a.Ho == a.Hs && a.Wo == a.Ws && !(a.C0 % 64) && !(a.C1 % 64) &&
            batch == 1 && (size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 < 0x7FFFFFFFull;
+}
+
+// folded-upsample form (round 6): nearest-2x upsample + 3x3 convolution, single source, output rows of at most 48 pixels, whole `bp`-pixel tiles
+// inside a sample
+bool ladi_igemm_halo_ups_eligible(const IGemmArgs& a, int batch, int bp) {
+    return a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.ups == 1 && a.Ho == 2 * a.Hs && a.Wo == 2 * a.Ws && a.Wo <= HALO_WMAX && !a.C1 && !a.src1 &&
+           !(a.C0 % 64) && batch == 1 && bp > 0 && !((a.Ho * a.Wo) % bp) && !(a.P % (a.Ho * a.Wo)) && (size_t)a.P * (size_t)a.ld0 * 2 < 0x7FFFFFFFull;
 }
 
 // 2-D blocked form: rows of any width that is a multiple of 32, whole blocks of `th` image rows
@@ -57,5 +67,9 @@ int ladi_launch_igemm_halo(const IGemmArgs& a, int tq, int tp, int nxb, int batc
     if (tq == 5 && tp == 2 && nxb == 20) return ladi_halo_launch_g320x256(a, batch, st);   // 320x256, 8 waves, 128 KB
     if (tq == 2 && tp == 2 && nxb == 21) return ladi_halo_launch_g128x128_w2(a, batch, st);   // 128x128 (4 rows x 32), 4 waves x 2 per CU, 60 KB
     if (tq == 2 && tp == 4 && nxb == 11) return ladi_halo_launch_f128x256_w2n(a, batch, st);      // 128x256, 4 waves (64 x 128 each: 0.75 KB of fragment reads per MFMA, half the weight DMA per MFMA of 128x128) x 2 per CU, rows <= 24 pixels (72 KB)
+    // round 6: folded-upsample forms (nxb 30: 4 waves x 2 per CU; 31: 12 waves)
+    if (tq == 2 && tp == 3 && nxb == 30) return ladi_halo_launch_u128x192(a, batch, st);
+    if (tq == 2 && tp == 2 && nxb == 30) return ladi_halo_launch_u128x128(a, batch, st);
+    if (tq == 5 && tp == 1 && nxb == 31) return ladi_halo_launch_u320x192_w6(a, batch, st);
     return -7;
 }

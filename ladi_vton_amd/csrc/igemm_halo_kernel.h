@@ -72,7 +72,14 @@ constexpr int nx_sum(int t, int D, bool pf) {
 // real halo columns (zero-filled by the descriptor's bounds check outside the image), the consumer needs no validity masks at all.  Staged
 // rows per chunk: (TH + 2) * 34 for TH * 32 pixels (1.33x at TH = 8) where the ring kernels stage 9x.  Requires W % 32 == 0, H % TH == 0
 // (whole blocks), a single halo buffer (NXB = 1); the epilogue sees sub-tiles one image row apart (igemm_epilogue pstr = W).
-template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48, int ONE = 0, int G2D = 0>
+// UPS = 1 (round 6): the nearest-2x upsample of Upsample2D FOLDED into the 3x3 convolution that follows it (diffusers Upsample2D: interpolate x 2 ->
+// conv; runtime ConvOpt::ups).  The source is the LOW-resolution image (Hs x Ws), the output 2 Hs x 2 Ws; tap (dy, dx) of output pixel (y, x) reads
+// source pixel ((y + dy - 1) >> 1, (x + dx - 1) >> 1).  The staged "halo tile" is the run of low-resolution image rows the tile's output rows touch
+// (a QUARTER of the pixels a plain halo tile stages), and the tap is applied at read time through two per-lane 3-entry tables (source row, source
+// column) instead of the linear shift.  The ring kernels did this layer with per-lane addressing of every tap's gather (12 VALU per DMA piece):
+// 948-955 TFLOP/s where the plain convolutions of the same size reach 1 180 (profiles/r05_unet_forward_kernel_stats.txt: the 382 / 379 us launches).
+// Requires whole tiles inside a sample (Ho Wo % BP == 0), a single source, an output row of at most WMAX pixels, one halo buffer.
+template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48, int ONE = 0, int G2D = 0, int UPS = 0>
 __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void igemm_halo_kernel(const IGemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only (see igemm_kernel.h)
     constexpr int WQ = 2, WP = WPN, BK = 64, NT = 128 * WPN;    // 8 waves (2 x 4), or 4 waves (2 x 2) with two workgroups per CU
@@ -81,6 +88,7 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
     constexpr int RQ = (BQ + RPP - 1) / RPP;                     // weight passes per tap
     constexpr int TH = BP / 32, HC = 34;                         // G2D: image rows per block, row pitch of the staged block (32 + 2 halo columns)
     static_assert(!G2D || NXB == 1, "the 2-D blocked form keeps one halo buffer");
+    static_assert(!UPS || (NXB == 1 && !G2D && !ONE), "the folded-upsample form: one halo buffer, linear tile");
     constexpr int XROWS = ((G2D ? (TH + 2) * HC : BP + 2 * WMAX + 2) + RPP - 1) / RPP * RPP;   // rows of one halo-tile buffer (whole passes)
     constexpr int LX = XROWS / RPP;                              // halo passes per channel chunk
     constexpr int WSLOT = RQ * RPP * BK;                         // halves per weight slot (padded to whole passes)
@@ -146,9 +154,10 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
     const int ldw = a.ldw ? a.ldw : a.K;
     // descriptors with the exact extent of each operand: rows before the first / after the last pixel of the tensor are zero-filled
     // (the launcher guarantees P * ld * 2 < 2^31)
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.src0), 0, (unsigned)((size_t)a.P * a.ld0 * 2), 0x00020000);
+    const int Psrc = UPS ? a.P / 4 : a.P;                        // pixels of the source tensor
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.src0), 0, (unsigned)((size_t)Psrc * a.ld0 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.src1 ? a.src1 : a.src0), 0,
-                                                                         (unsigned)((size_t)a.P * (a.src1 ? a.ld1 : a.ld0) * 2), 0x00020000);
+                                                                         (unsigned)((size_t)Psrc * (a.src1 ? a.ld1 : a.ld0) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.W), 0, 0x7FFFFFFF, 0x00020000);
 
     // ---- DMA-side per-lane offsets (constant over the K loop)
@@ -159,6 +168,17 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
         const int clog = c8 ^ ((row >> 1) & 7);
         wbase[i] = (row < BQ && q < a.Q) ? (unsigned)(((size_t)q * ldw + clog * 8) * 2) : OOB;
     }
+    // UPS: the tile lies inside sample u_n (launcher: Ho Wo % BP == 0); its output rows u_y0 .. u_y1 touch the source rows (u_y0 - 1) >> 1 ..
+    // (u_y1 + 1) >> 1; halo-tile row r = source pixel u_l0 + r of that sample (u_l0 < 0 on the first tile: rows in front of the image are zero-filled)
+    int u_n = 0, u_q0 = 0, u_r0 = 0, u_l0 = 0, u_rows = 0;
+    if constexpr (UPS) {
+        const int Wo = 2 * Ws, HWo = 4 * HW;
+        u_n = p0 / HWo; u_q0 = p0 - u_n * HWo;
+        const int y0 = u_q0 / Wo, y1 = (u_q0 + BP - 1) / Wo;
+        u_r0 = (y0 - 1) >> 1;
+        u_l0 = u_r0 * Ws;
+        u_rows = (((y1 + 1) >> 1) - u_r0 + 1) * Ws;               // staged rows actually read (the passes beyond them are skipped)
+    }
     unsigned xo0[LX], xo1[LX];
 #pragma unroll
     for (int i = 0; i < LX; ++i) {
@@ -166,6 +186,11 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
         long long pin = (long long)p0 - Ws - 1 + row;
         const int clog = c8 ^ ((row >> 1) & 7);
         bool ok = pin >= 0 && pin < a.P;
+        if constexpr (UPS) {
+            const int lin = u_l0 + row;
+            ok = lin >= 0 && lin < HW && row < u_rows;
+            pin = (long long)u_n * HW + lin;
+        }
         if constexpr (G2D) {                                     // row = (block row rr, block column cc) of the (TH + 2) x 34 block
             const int rr = row / HC, cc = row - rr * HC;
             const int y = g_y0 - 1 + rr, x = g_x0 - 1 + cc;
@@ -177,11 +202,24 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
     }
     // ---- consumer-side: this lane's pixel in each of its TP blocks: halo-tile row of the centre tap and the 9-bit validity mask
     int rb[TP]; unsigned vm[TP];
+    int uyr[UPS ? TP : 1][3], uxr[UPS ? TP : 1][3];             // UPS: halo-tile row offset of source row (y + d - 1) >> 1, source column (x + d - 1) >> 1
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int pl = (wp * TP + j) * 32 + l31, p = p0 + pl;
         rb[j] = G2D ? (wp * TP + j + 1) * HC + l31 + 1 : pl + Ws + 1;
         unsigned m = G2D ? 0x1ffu : 0u;                          // G2D: whole blocks inside the image, out-of-image taps are zero-filled halo pixels
+        if constexpr (UPS) {
+            const int Wo = 2 * Ws, Ho = 2 * Hs;
+            const int q = u_q0 + pl, oy = q / Wo, ox = q - oy * Wo;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                uyr[j][d] = (((oy + d - 1) >> 1) - u_r0) * Ws;
+                uxr[j][d] = (ox + d - 1) >> 1;
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if ((unsigned)(oy + t / 3 - 1) < (unsigned)Ho && (unsigned)(ox + t % 3 - 1) < (unsigned)Wo) m |= 1u << t;
+        } else
         if (!G2D && p < a.P) {
             const int rem = p % HW, oy = rem / Ws, ox = rem - oy * Ws;
 #pragma unroll
@@ -216,7 +254,7 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
         char* base = smem_raw + (size_t)(NSTW * WSLOT + (NXB == 2 ? (chunk & 1) : 0) * XBUF) * 2 + wave * 1024;
 #pragma unroll
         for (int i = 0; i < LX; ++i)
-            if (i >= i0 && i < i1)
+            if (i >= i0 && i < i1 && (!UPS || i * RPP < u_rows))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(base + i * (RPP * BK * 2)), 16, s0 ? xo0[i] : xo1[i], so, 0, 0);
     };
 
@@ -271,7 +309,8 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
                     const bool valid = (vm[j] >> t) & 1u;
-                    const int row = rb[j] + tshift;
+                    int row = rb[j] + tshift;
+                    if constexpr (UPS) row = uyr[j][t / 3] + uxr[j][t % 3];
                     xoff[j] = valid ? (int)(sX - smem) + row * 64 : ZOFF;
                     xsw[j] = valid ? ((row >> 1) & 7) : 0;
                 }
@@ -326,13 +365,18 @@ __global__ __launch_bounds__(128 * WPN, (ONE ? 1 : (WPN == 6 ? 3 : 2))) void ige
 #endif
 }
 
-template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48, int ONE = 0, int G2D = 0>
+template <int TQ, int TP, int NXB, int NSTW, int WPN, int WMAX = 48, int ONE = 0, int G2D = 0, int UPS = 0>
 int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
     constexpr int BQ = 64 * TQ, BP = 32 * WPN * TP, RPP = 16 * WPN;
     constexpr int RQ = (BQ + RPP - 1) / RPP, XROWS = ((G2D ? (BP / 32 + 2) * 34 : BP + 2 * WMAX + 2) + RPP - 1) / RPP * RPP;
     constexpr int SMEM = (NSTW * RQ * RPP * 64 + NXB * XROWS * 64) * (int)sizeof(h16) + 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget of one CU");
     static_assert(SMEM >= igemm_epilogue_lds_bytes<2, WPN, TQ>(), "epilogue patches must fit");
+    if (UPS) {
+        if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || !a.ups || 2 * a.Ws > WMAX || a.Ho != 2 * a.Hs || a.Wo != 2 * a.Ws || a.C1 || a.src1) return -16;
+        if (((a.Ho * a.Wo) % BP) || (a.P % (a.Ho * a.Wo))) return -16;                       // whole tiles inside a sample
+        if ((((BP + 2 * a.Ws - 1) / (2 * a.Ws) + 2) / 2 + 2) * a.Ws > XROWS) return -16;     // source rows a tile can touch (generous bound)
+    } else
     if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups || (!G2D && a.Ws > WMAX) || a.Ho != a.Hs || a.Wo != a.Ws) return -16;
     if ((a.C0 % 64) || (a.C1 % 64) || (batch != 1 && a.splitk <= 1)) return -16;
     if (G2D && ((a.Ws % 32) || (a.Hs % (BP / 32)) || batch != 1 || a.splitk > 1)) return -16;   // whole (BP / 32) x 32 blocks, no split-K
@@ -345,7 +389,7 @@ int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
     }
     if ((size_t)a.P * (size_t)std::max(a.ld0, a.ld1) * 2 >= 0x7FFFFFFFull) return -16;   // 32-bit byte offsets from the tensor base
     static unsigned long long attr_done = 0;
-    auto kfn = igemm_halo_kernel<TQ, TP, NXB, NSTW, WPN, WMAX, ONE, G2D>;
+    auto kfn = igemm_halo_kernel<TQ, TP, NXB, NSTW, WPN, WMAX, ONE, G2D, UPS>;
     if (ladi_ensure_dyn_lds(reinterpret_cast<const void*>(kfn), SMEM, attr_done)) return -10;
     const int nq = (a.Q + BQ - 1) / BQ, np = (a.P + BP - 1) / BP;
     int blocks = nq * np;
@@ -362,7 +406,7 @@ int launch_halo(IGemmArgs a, int batch, hipStream_t st) {
     {
         static const int mode = [] { const char* e = getenv("LADI_HALO_MAP3"); return e ? atoi(e) : 1; }();
         const bool off = mode == 0 || (mode != 2 && np <= 12);
-        const size_t wbytes = (size_t)a.Q * a.K * 2, xbytes = (size_t)a.P * (a.C0 + a.C1) * 2;
+        const size_t wbytes = (size_t)a.Q * a.K * 2, xbytes = (size_t)(UPS ? a.P / 4 : a.P) * (a.C0 + a.C1) * 2;
         const int S = a.splitk > 1 ? a.splitk : 1;
         if (!off && !G2D && (batch == 1 || a.splitk > 1) && wbytes >= 3 * xbytes && np <= 32 && np >= 2) {
             const int G = np <= 12 ? np : (np + 1) / 2;

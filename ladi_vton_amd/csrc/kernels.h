@@ -26,7 +26,8 @@ int ladi_launch_igemm_lc(const IGemmArgs& a, int tq, int tp, int nst, int batch,
 
 // ---- igemm_halo.hip: halo-resident 3x3 convolution, workgroup tile (64 tq) x (128 tp), nxb halo buffers
 bool ladi_igemm_halo_eligible(const IGemmArgs& a, int batch);
-bool ladi_igemm_halo2d_eligible(const IGemmArgs& a, int batch, int th);   // 2-D blocked form (nxb 20 / 21): W % 32 == 0, H % th == 0
+bool ladi_igemm_halo2d_eligible(const IGemmArgs& a, int batch, int th);
+bool ladi_igemm_halo_ups_eligible(const IGemmArgs& a, int batch, int bp);   // folded nearest-2x upsample + 3x3 (round 6)   // 2-D blocked form (nxb 20 / 21): W % 32 == 0, H % th == 0
 int ladi_launch_igemm_halo(const IGemmArgs& a, int tq, int tp, int nxb, int batch, hipStream_t st);
 
 // ---- linear_xs.hip: X-stationary kernel for 1x1 layers with K = 320 / 640 (reached through ladi_launch_igemm cfg 23..27)

@@ -226,6 +226,16 @@ struct VAE {
     // with a larger shift when the overflow flag came back set; returns the shift that was used.  Synchronises the stream once.
     template <typename Body> int decode_guarded(hipStream_t st, Body&& body);
     bool overflowed(hipStream_t st);     // reads (and clears) d_bad; synchronises `st`
+    // Deferred form of the guard for the fused pipeline (round 6; VERDICT r04 / r05: the run used to end in a D2H copy + hipStreamSynchronize of
+    // the flag on every call).  A run decodes ONCE, at guard_shift(), and post_overflow_check() queues flag -> pinned host word, flag reset and
+    // an event behind it: no host round trip.  poll_overflow() -- called at the entry of the next run and by ladi_tryon_poll_overflow() --
+    // waits for that event (long complete by then), and if the flag was set raises the automatic shift (0 -> 4 -> 8) and reports 1: the
+    // images of THAT run are invalid and the caller re-submits it (pipeline.py does so transparently when it hands out host results; with
+    // device-resident results the next call fails loudly instead of returning garbage).
+    int auto_shift = 0; int* h_bad = nullptr; hipEvent_t ev_bad = nullptr; bool bad_pending = false;
+    int guard_shift() const { return range_shift >= 0 ? range_shift : auto_shift; }
+    void post_overflow_check(hipStream_t st);
+    int poll_overflow();                 // 0: nothing pending / last checked run was fine; 1: it overflowed (automatic shift raised if possible)
     ~VAE();
 };
 

@@ -47,6 +47,14 @@ int TryOn::run(const TryOnInputs& in, void* images_out, int images_u8, float* la
         HIP_OK(hipStreamWaitEvent(own_stream, ev_in, 0));
         st = own_stream;
     } catch (const std::exception& e) { set_error(std::string("tryon: ") + e.what()); return -100; }
+    try {
+        if (vae->poll_overflow()) {      // the PREVIOUS run's decode left the fp16 range: its images are invalid and nobody asked (ladi_tryon_poll_overflow)
+            set_error("tryon: the previous run's VAE decode overflowed the fp16 range (non-finite GroupNorm statistics) at range shift " + std::to_string(vae->last_shift) +
+                      "; its images are invalid -- re-submit that batch (the automatic shift is now " + std::to_string(vae->guard_shift()) + ")");
+            (void)hipEventRecord(ev_out, st); (void)hipStreamWaitEvent(user_st, ev_out, 0);
+            return -101;
+        }
+    } catch (const std::exception& e) { set_error(std::string("tryon: ") + e.what()); return -100; }
     const int B = in.batch, H = in.height, W = in.width;
     if (H % 8 || W % 8) { set_error("height and width must be divisible by 8"); return -2; }
     const int h = H / 8, w = W / 8, hw = h * w;
@@ -217,13 +225,16 @@ int TryOn::run(const TryOnInputs& in, void* images_out, int images_u8, float* la
                     c.stats_off = 0;
                     (void)vae->decode(c, z, use_emasc ? skips : nullptr, vae->range_shift < 0 ? 4 : vae->range_shift);
                 } else {
-                    (void)vae->decode_guarded(st, [&](int sh) {
-                        arena.release(mk_dec);
-                        c.stats_off = 0;
-                        if (stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
-                        Act img = vae->decode(c, z, use_emasc ? skips : nullptr, sh);
-                        c.check(ladi_launch_image_post(img.p, img.ld, B * H * W, images_out, images_u8, st), "image_post");
-                    });
+                    // ONE decode at the guard's current shift; the flag is examined without a host round trip (runtime.h VAE::post_overflow_check /
+                    // poll_overflow: at the entry of the next run, or by ladi_tryon_poll_overflow)
+                    const int sh = vae->guard_shift();
+                    arena.release(mk_dec);
+                    c.stats_off = 0;
+                    if (stats_cap) HIP_OK(hipMemsetAsync(stats, 0, stats_cap * sizeof(float), st));
+                    Act img = vae->decode(c, z, use_emasc ? skips : nullptr, sh);
+                    c.check(ladi_launch_image_post(img.p, img.ld, B * H * W, images_out, images_u8, st), "image_post");
+                    vae->last_shift = sh;
+                    vae->post_overflow_check(st);
                     if (latents_out) c.check(ladi_launch_lat_pix_to_nchw(latents, B, hw, latents_out, st), "latents_out");
                     HIP_OK(hipEventRecord(ev[3], st));
                     ev_valid = true;

@@ -89,7 +89,34 @@ void VAE::load(const VAECfg& c, const WeightStore& ws) {
     if (hipMemset(d_bad, 0, 256) != hipSuccess) throw std::runtime_error("VAE: overflow flag");
 }
 
-VAE::~VAE() { if (stats) (void)hipFree(stats); }
+VAE::~VAE() {
+    if (stats) (void)hipFree(stats);
+    if (h_bad) (void)hipHostFree(h_bad);
+    if (ev_bad) (void)hipEventDestroy(ev_bad);
+}
+
+void VAE::post_overflow_check(hipStream_t st) {
+    if (!d_bad) return;
+    if (!h_bad) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&h_bad), sizeof(int)) != hipSuccess || hipEventCreateWithFlags(&ev_bad, hipEventDisableTiming) != hipSuccess)
+            throw std::runtime_error("VAE: allocating the overflow-flag mailbox failed");
+        *h_bad = 0;
+    }
+    if (hipMemcpyAsync(h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipMemsetAsync(d_bad, 0, sizeof(int), st) != hipSuccess ||
+        hipEventRecord(ev_bad, st) != hipSuccess)
+        throw std::runtime_error("VAE: queueing the overflow-flag copy failed");
+    bad_pending = true;
+}
+
+int VAE::poll_overflow() {
+    if (!bad_pending) return 0;
+    bad_pending = false;
+    if (hipEventSynchronize(ev_bad) != hipSuccess) throw std::runtime_error("VAE: waiting for the overflow flag failed");
+    if (!*h_bad) return 0;
+    *h_bad = 0;
+    if (range_shift < 0 && auto_shift < 8) auto_shift = auto_shift == 0 ? 4 : 8;     // the re-submitted run gets 2^4 (then 2^8) more head-room
+    return 1;
+}
 
 namespace {
 

@@ -240,6 +240,21 @@ class StableDiffusionTryOnePipeline:
             check(lib.ladi_tryon_set_lanes(self._tryon, int(lanes if lanes is not None else self.lanes)), "ladi_tryon_set_lanes")
         run = lib.ladi_tryon_run_u8 if out_uint8 else lib.ladi_tryon_run
         check(run(self._tryon, ctypes.byref(inp), ptr(images), ptr(self.last_latents), stream_ptr()), "ladi_tryon_run")
+        if not return_device:
+            # results go to the host: this is the synchronisation point anyway, so the decode's fp16-range guard is asked now (a run decodes
+            # once and queues its flag; no host round trip inside the run).  An overflow raised the automatic range shift: run the batch again.
+            # With return_device the flag is examined by the next call instead (or by check_overflow()), which fails loudly rather than hand out
+            # a bad batch silently.
+            for _ in range(2):
+                po = lib.ladi_tryon_poll_overflow(self._tryon)
+                if po == 0:
+                    break
+                if po < 0:
+                    raise _lib.NativeError("ladi_tryon_poll_overflow: " + _lib.last_error())
+                check(run(self._tryon, ctypes.byref(inp), ptr(images), ptr(self.last_latents), stream_ptr()), "ladi_tryon_run (re-run at a larger range shift)")
+            else:
+                if lib.ladi_tryon_poll_overflow(self._tryon) != 0:
+                    raise _lib.NativeError("VAE decode: activations exceed the fp16 range even at range shift 8")
         if tr is not None:   # [evals, B, 4, h, w] like the reference's noise_pred / latents (tryon_pipe.py:732-740)
             nchw = tr.view(2, self.trace_evals, B, h8, w8, 4).permute(0, 1, 2, 5, 3, 4)
             self.last_trace = dict(noise_pred=nchw[0].contiguous(), latents=nchw[1].contiguous())
@@ -250,6 +265,16 @@ class StableDiffusionTryOnePipeline:
         if lib.ladi_tryon_stage_ms(self._tryon, ms) == 0:
             self.last_stage_ms = list(ms)
         return out
+
+    def check_overflow(self):
+        """True if the last fused run's decode left the fp16 range (its images are invalid; the automatic range shift has been raised, so running
+        the batch again gives the result).  For callers that keep results on the device (return_device=True): waits for the run to finish."""
+        if not self._tryon:
+            return False
+        po = _lib.load().ladi_tryon_poll_overflow(self._tryon)
+        if po < 0:
+            raise _lib.NativeError("ladi_tryon_poll_overflow: " + _lib.last_error())
+        return po == 1
 
     def lib_lanes(self):
         """sample-group lanes the last fused run used"""

@@ -285,18 +285,19 @@ def test_igemm_tile_table_names_every_configuration(lib):
     """host side of the GEMM family: every tile configuration 1..ladi_igemm_cfg_count() maps to the kernel symbol rocprofv3 reports for it
     (bench.py groups its roofline by these names; profiles/r03_*), the table has the size the docs quote, and each kernel family is present"""
     n = lib.ladi_igemm_cfg_count()
-    assert n == 103
+    assert n == 108
     names = [lib.ladi_igemm_cfg_symbol_name(c).decode() for c in range(1, n + 1)]
     # the X-stationary configurations name their family only: the template arguments depend on the launch (K, LayerNorm, epilogue mode) and
     # are resolved per recorded launch by ladi_profile_igemm_symbols
     assert all(re.fullmatch(r"(igemm_kernel|igemm8_kernel|igemm_lc_kernel|igemm_halo_kernel)<[0-9a-z, ]+>|linear_xs_kernel", s) for s in names), names
     fam = {s.split("<")[0] for s in names}
     assert fam == {"igemm_kernel", "igemm8_kernel", "igemm_lc_kernel", "igemm_halo_kernel", "linear_xs_kernel"}, fam
-    assert names[84 - 1] == "igemm_halo_kernel<2, 2, 1, 2, 2, 48, 0, 0>"    # the dominant symbol of the round-3 forward (profiles/r03_bench_default.json)
-    assert names[92 - 1] == "igemm_halo_kernel<5, 1, 1, 2, 6, 48, 0, 0>"    # round 4: the 12-wave 320x192 form (256 workgroups on the 64x48 level)
+    assert names[84 - 1] == "igemm_halo_kernel<2, 2, 1, 2, 2, 48, 0, 0, 0>"    # the dominant symbol of the round-3 forward (profiles/r03_bench_default.json)
+    assert names[92 - 1] == "igemm_halo_kernel<5, 1, 1, 2, 6, 48, 0, 0, 0>"    # round 4: the 12-wave 320x192 form (256 workgroups on the 64x48 level)
     # round 6: halo symbols carry EVERY template argument, as rocprofv3 prints them, so that a ring-halo form and the 2-D blocked form of the same
     # leading arguments (cfg 75 / 101) can never be taken for each other when bench.py looks a symbol up in a committed trace (ADVICE r05)
-    assert names[75 - 1] == "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 0>" and names[101 - 1] == "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 1>"
+    assert names[75 - 1] == "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 0, 0>" and names[101 - 1] == "igemm_halo_kernel<4, 2, 1, 3, 4, 48, 0, 1, 0>"
+    assert names[105 - 1] == "igemm_halo_kernel<5, 1, 1, 2, 6, 48, 0, 0, 1>"      # round 6: the folded-upsample forms (UPS = 1)
     assert not lib.ladi_igemm_cfg_symbol_name(0) and not lib.ladi_igemm_cfg_symbol_name(n + 1)   # out of range: empty, not a crash
 
 
@@ -839,10 +840,10 @@ def test_bench_hbm_kernels_reads_the_committed_profiles(monkeypatch):
     ga = h["unet_forward"]["gn_norm_kernel"]          # round 5: the UNet's GroupNorms are one-pass launches (finalize folded into apply)
     assert 500.0 < ga["GBps"] < 8000.0 and abs(ga["GBps"] - ga["MB_per_launch"] * 1e3 / ga["avg_us"]) < 1.0, ga
     assert any("gn_" in k for k in h["vae_stages"]) and "source" in h      # (round 6: the VAE's GroupNorms are gn_reduce_rows + gn_norm launches)
-    t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24, 0, 0>")
+    t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24, 0, 0, 0>")
     assert why is None and abs(t["bytes_per_launch"] - (t["fetch_bytes_x2"] + t["write_bytes"])) <= 2 and t["bytes_per_launch"] > 10_000_000   # each term is rounded on its own
     monkeypatch.setattr(bench, "lib_digest", lambda: "another-build")
-    t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24, 0, 0>")
+    t, why = bench.traffic_committed("igemm_halo_kernel<2, 2, 1, 3, 2, 24, 0, 0, 0>")
     assert t is None and "stale" in why
     assert "note" in bench.hbm_kernels()["unet_forward"]
 

@@ -450,6 +450,42 @@ def test_conv3x3_upsample_fold():
     assert U.rel_l2(U.to_nchw(y), ref) < TOL
 
 
+@pytest.mark.parametrize("cfg,N,cin,cout,hw", [(104, 2, 128, 128, (8, 12)),      # 128x192 tiles: 16x24 output = 384 pixels per sample, two tiles each
+                                               (104, 1, 192, 320, (12, 24)),     # 24x48 output rows (the widest the form takes), ragged channel tile
+                                               (106, 2, 128, 64, (16, 12)),      # 128x128 tiles, tile boundaries in the middle of image rows
+                                               (106, 3, 64, 128, (4, 8)),        # 8x16 output = exactly one tile per sample
+                                               (105, 1, 128, 320, (12, 8)),      # twelve-wave 320x192 tile, 24x16 output = two tiles
+                                               (107, 2, 1152, 128, (8, 12)),     # cfg 104 + split-K 2 (K = 10 368: 162 steps, slices enter chunks mid-way)
+                                               (108, 2, 1280, 128, (8, 8))])     # cfg 106 + split-K 2
+def test_conv3x3_upsample_fold_halo_forms(cfg, N, cin, cout, hw):
+    """round 6: the halo kernel's folded-upsample forms (igemm_halo_kernel.h UPS = 1: the LOW-resolution rows a tile touches are staged once per
+    channel chunk, the tap is a per-lane (row, column) table look-up) against interpolate(nearest, x2) -> conv2d, with bias + residual; first /
+    last rows and columns (out-of-image taps), tiles that start in the middle of an image row, several samples, split-K; repeat launches bit-equal"""
+    h, w = hw
+    x, wt, b = _rand((N, cin, h, w), 110), _rand((cout, cin, 3, 3), 111, 0.05), _rand((cout,), 112, 0.1)
+    skip = _rand((N, cout, 2 * h, 2 * w), 113)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, b, padding=1) + skip
+    xs, ws, rs = U.nhwc16(x), U.pack_conv_weight(wt), U.nhwc16(skip)
+    y = U.igemm(xs, ws, cout, ups=1, bias=b, res0=rs, cfg=cfg)
+    assert U.rel_l2(U.to_nchw(y), ref) < TOL
+    y2 = U.igemm(xs, ws, cout, ups=1, bias=b, res0=rs, cfg=cfg)
+    assert torch.equal(y, y2)
+    y_ring = U.igemm(xs, ws, cout, ups=1, bias=b, res0=rs, cfg=7)      # the ring kernel's per-lane gather of the same layer
+    assert U.rel_l2(U.to_nchw(y), U.to_nchw(y_ring).float()) < TOL
+
+
+def test_conv3x3_upsample_fold_halo_refuses_what_it_cannot_do():
+    """two sources, an output row wider than 48 pixels, or a sample that is not whole tiles: the folded-upsample halo forms must refuse (rc != 0)"""
+    lib = __import__("ladi_vton_amd")._lib.load()
+    x, wt = _rand((1, 128, 12, 32), 114), _rand((64, 128, 3, 3), 115, 0.05)
+    with pytest.raises(AssertionError):
+        U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), 64, ups=1, cfg=104)             # 64-pixel output rows
+    x = _rand((1, 128, 6, 6), 116)
+    with pytest.raises(AssertionError):
+        U.igemm(U.nhwc16(x), U.pack_conv_weight(wt), 64, ups=1, cfg=106)             # 144 output pixels per sample: not whole 128-pixel tiles
+    del lib
+
+
 def test_conv_concat_two_sources_and_1x1():
     N, c0, c1, cout, h, w = 2, 128, 64, 128, 12, 8
     a, b2 = _rand((N, c0, h, w), 14), _rand((N, c1, h, w), 15)

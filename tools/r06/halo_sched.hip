@@ -30,12 +30,16 @@
 #ifndef HS_G2D
 #define HS_G2D 0
 #endif
+#ifndef HS_UPS
+#define HS_UPS 0          /* 1: folded nearest-2x upsample; H, W on the command line are the OUTPUT size */
+#endif
 
 int main(int argc, char** argv) {
     const int n = argc > 6 ? atoi(argv[6]) : 16, H = argc > 1 ? atoi(argv[1]) : 32, W = argc > 2 ? atoi(argv[2]) : 24, C = argc > 3 ? atoi(argv[3]) : 640, Q = argc > 4 ? atoi(argv[4]) : 640;
     const int splitk = argc > 5 ? atoi(argv[5]) : 1;
     const int P = n * H * W, K = 9 * C;
-    std::vector<h16> hx((size_t)P * C), hw((size_t)Q * K), hb(Q), hr((size_t)P * Q);
+    const int Hs = HS_UPS ? H / 2 : H, Ws = HS_UPS ? W / 2 : W, Ps = n * Hs * Ws;
+    std::vector<h16> hx((size_t)Ps * C), hw((size_t)Q * K), hb(Q), hr((size_t)P * Q);
     unsigned s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((float)((s >> 9) & 0xffff) / 65536.f - 0.5f); };
     for (auto& v : hx) v = (h16)(rnd() * 2.f);
@@ -49,12 +53,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dres, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
     IGemmArgs a = {};
-    a.src0 = dx; a.C0 = C; a.ld0 = C; a.Hs = H; a.Ws = W; a.Ho = H; a.Wo = W; a.P = P; a.ksize = 3; a.stride = 1; a.pad = 1;
+    a.src0 = dx; a.C0 = C; a.ld0 = C; a.Hs = Hs; a.Ws = Ws; a.Ho = H; a.Wo = W; a.P = P; a.ksize = 3; a.stride = 1; a.pad = 1; a.ups = HS_UPS;
     a.W = dw; a.Q = Q; a.K = K; a.bias = db; a.act = LADI_ACT_NONE; a.out_scale = 1.f; a.out = dout; a.ldo = Q; a.splitk = splitk;
     a.res0 = dres; a.ldr0 = Q;
     if (splitk > 1) { a.sk_ws = dws; a.sk_cnt = dcnt; }
     hipStream_t st; CK(hipStreamCreate(&st));
-    auto launch = [&]() { return launch_halo<HS_TQ, HS_TP, HS_NXB, HS_NSTW, HS_WPN, HS_WMAX, HS_ONE, HS_G2D>(a, splitk > 1 ? splitk : 1, st); };
+    auto launch = [&]() { return launch_halo<HS_TQ, HS_TP, HS_NXB, HS_NSTW, HS_WPN, HS_WMAX, HS_ONE, HS_G2D, HS_UPS>(a, splitk > 1 ? splitk : 1, st); };
     for (int i = 0; i < 3; ++i) if (int rc = launch()) { printf("launch failed %d\n", rc); return 1; }
     CK(hipStreamSynchronize(st));
     std::vector<h16> o1((size_t)P * Q), o2((size_t)P * Q);
@@ -75,7 +79,7 @@ int main(int argc, char** argv) {
         for (int t = 0; t < 9; ++t) {
             const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
             if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-            const h16* xp = &hx[((size_t)(nn * H + iy) * W + ix) * C];
+            const h16* xp = HS_UPS ? &hx[((size_t)(nn * Hs + (iy >> 1)) * Ws + (ix >> 1)) * C] : &hx[((size_t)(nn * H + iy) * W + ix) * C];
             const h16* wp = &hw[(size_t)q * K + (size_t)t * C];
             for (int c = 0; c < C; ++c) acc += (double)(float)xp[c] * (double)(float)wp[c];
         }
@@ -97,8 +101,8 @@ int main(int argc, char** argv) {
         best = fminf(best, ms); sum += ms;
     }
     const double us = best * 1000.0 / iters, gf = 2.0 * P * Q * (double)K / 1e9;
-    printf("SCHED %2d <%d,%d,%d,%d,%d,%d,%d,%d> n%d %dx%d %d->%d sk%d  best %7.1f us (mean %7.1f)  %6.0f TFLOP/s  rel-L2 %.2e  max|d| %.3g  repeat-bit-equal %s  %s\n",
-           LADI_HALO_SCHED, HS_TQ, HS_TP, HS_NXB, HS_NSTW, HS_WPN, HS_WMAX, HS_ONE, HS_G2D, n, H, W, C, Q, splitk, us, sum / 3 * 1000.0 / iters, gf / us * 1e3, rel, worst,
+    printf("SCHED %2d <%d,%d,%d,%d,%d,%d,%d,%d,%d> n%d %dx%d %d->%d sk%d  best %7.1f us (mean %7.1f)  %6.0f TFLOP/s  rel-L2 %.2e  max|d| %.3g  repeat-bit-equal %s  %s\n",
+           LADI_HALO_SCHED, HS_TQ, HS_TP, HS_NXB, HS_NSTW, HS_WPN, HS_WMAX, HS_ONE, HS_G2D, HS_UPS, n, H, W, C, Q, splitk, us, sum / 3 * 1000.0 / iters, gf / us * 1e3, rel, worst,
            same ? "yes" : "NO", (rel < 2e-3 && same) ? "OK" : "FAIL");
     return (rel < 2e-3 && same) ? 0 : 2;
 }
