@@ -113,7 +113,7 @@ struct CfgInfo { int bq, bp, blocks_per_cu; bool geglu_ok; float eff; int tp; in
 // tile configurations (0 = choose: measured per shape when autotuning is on, else the cost model below).
 // {bq, bp, workgroups per CU (cost model), GEGLU-capable, cost-model efficiency (0 = measured selection only), tp, base kernel, split-K,
 //  K step, offered to the tuner}
-constexpr int NCFG = 108;
+constexpr int NCFG = 109;
 const CfgInfo kCfg[NCFG + 1] = {
     {0, 0, 0, false, 0.f, 0, 0, 1, 0, false},
     {128, 256, 2, true, 0.80f, 4, 1, 1, 32, true},   // 1: <2,2,2,4> BK32 NST3
@@ -250,6 +250,9 @@ const CfgInfo kCfg[NCFG + 1] = {
     {128, 128, 2, false, 0.00f, 2, 106, 1, 64, true},  // 106: halo-ups 128x128, 4 waves, two workgroups per CU
     {128, 192, 2, false, 0.00f, 3, 104, 2, 64, true},  // 107: cfg 104 + split-K 2
     {128, 128, 2, false, 0.00f, 2, 106, 2, 64, true},  // 108: cfg 106 + split-K 2
+    // 109 (round 6): the 8x6 level's convolutions are chains of 45 dependent K steps per slice at split 4 (latency, not bandwidth: profiles/r06_halo_map3.txt);
+    // split 8 on the two-workgroups-per-CU form halves the chain (480 workgroups = one round) at the price of twice the slab traffic -- offered, the tuner decides
+    {128, 128, 2, false, 0.00f, 2, 88, 8, 64, true},   // 109: cfg 88 + split-K 8
 };
 inline bool is_xs(int base) { return base == 23 || base == 93; }
 inline int xs_nst(int base) { return base == 93 ? 2 : 3; }

@@ -285,7 +285,7 @@ def test_igemm_tile_table_names_every_configuration(lib):
     """host side of the GEMM family: every tile configuration 1..ladi_igemm_cfg_count() maps to the kernel symbol rocprofv3 reports for it
     (bench.py groups its roofline by these names; profiles/r03_*), the table has the size the docs quote, and each kernel family is present"""
     n = lib.ladi_igemm_cfg_count()
-    assert n == 108
+    assert n == 109
     names = [lib.ladi_igemm_cfg_symbol_name(c).decode() for c in range(1, n + 1)]
     # the X-stationary configurations name their family only: the template arguments depend on the launch (K, LayerNorm, epilogue mode) and
     # are resolved per recorded launch by ladi_profile_igemm_symbols

@@ -231,7 +231,7 @@ def test_conv3x3_split_k(cfg):
         assert torch.equal(U.igemm(X, Wp, cout, bias=b, rowadd=temb, act="silu", res0=R, cfg=cfg), y)
 
 
-@pytest.mark.parametrize("cfg", [87, 91, 83, 80, 13, 38])
+@pytest.mark.parametrize("cfg", [87, 91, 109, 83, 80, 13, 38])
 def test_split_k_in_launch_combine_at_the_8x6_level(cfg):
     """the launch population the in-launch combine was built for: the 1280 -> 1280 3x3 convolution of the 8x6 level at the bench batch
     (768 pixels: 60-120 tiles x 4-8 K slices spread over every XCD), residual epilogue, 30 launches back to back -- every output must equal
@@ -327,7 +327,7 @@ def test_fused_output_statistics(cfg):
     assert U.rel_l2(tot[:, 0], o.sum(0).cpu()) < 1e-4 and U.rel_l2(tot[:, 1], (o * o).sum(0).cpu()) < 1e-4
 
 
-HALO_W24 = [88, 89, 90, 91, 97, 98, 99]     # halo buffer sized for rows of <= 24 pixels (third weight slot at two workgroups per CU)
+HALO_W24 = [88, 89, 90, 91, 97, 98, 99, 109]     # halo buffer sized for rows of <= 24 pixels (third weight slot at two workgroups per CU)
 
 
 @pytest.mark.parametrize("cfg", HALO + [79, 80, 86] + HALO_W24 + [92, 96])

@@ -1,4 +1,4 @@
-# round 5 (as round 4): L2 hit-rate pass of the roofline command and the three counter passes of the 3 072-token self-attention (separate GPU call, same binary)
+# round 6 (as rounds 4 and 5): L2 hit-rate pass of the roofline command and the three counter passes of the 3 072-token self-attention (separate GPU call, same binary)
 cd $GRAFT_REPO_ROOT 2>/dev/null || cd /root/repo
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 DIG=$(cat ladi_vton_amd/csrc/_obj/stamp)
@@ -11,8 +11,8 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ
   timeout 200 rocprofv3 --pmc $set --kernel-trace -d $O/pa$i -- python $R/tools/bench_attn.py --attn-only --only self_L0 > /dev/null 2>&1
 done
 cd $R
-python tools/rocpd_pmc.py $(find $O/pmc_l2 -name "*.db" | head -1) $O/r05_pmc_l2.txt --digest $DIG > /dev/null
-python tools/rocpd_pmc.py $(find $O/pmc_lds -name "*.db" | head -1) $O/r05_pmc_lds.txt --digest $DIG > /dev/null
-for i in 1 2 3; do python tools/rocpd_pmc.py $(find $O/pa$i -name "*.db" | head -1) $O/r05_attn_pmc_$i.txt --digest $DIG > /dev/null; rm -rf $O/pa$i; done
+python tools/rocpd_pmc.py $(find $O/pmc_l2 -name "*.db" | head -1) $O/r06_pmc_l2.txt --digest $DIG > /dev/null
+python tools/rocpd_pmc.py $(find $O/pmc_lds -name "*.db" | head -1) $O/r06_pmc_lds.txt --digest $DIG > /dev/null
+for i in 1 2 3; do python tools/rocpd_pmc.py $(find $O/pa$i -name "*.db" | head -1) $O/r06_attn_pmc_$i.txt --digest $DIG > /dev/null; rm -rf $O/pa$i; done
 rm -rf $O/pmc_l2 $O/pmc_lds
-head -8 $O/r05_pmc_l2.txt | cut -c1-200; head -5 $O/r05_attn_pmc_3.txt | cut -c1-220
+head -8 $O/r06_pmc_l2.txt | cut -c1-200; head -5 $O/r06_attn_pmc_3.txt | cut -c1-220
