@@ -8,7 +8,9 @@ R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
 DIG=$(cat ladi_vton_amd/csrc/_obj/stamp)
-# ---- 1. tile selections for the BASELINE batch sizes (shipped as ladi_vton_amd/tune_gfx950.txt)
+# ---- 1. tile selections for the BASELINE batch sizes (shipped as ladi_vton_amd/tune_gfx950.txt); LADI_PROFILE_KEEP_TABLE=1 keeps the committed table
+#         (a second profile call on another box must measure the table the parity record was taken with)
+if [ -z "${LADI_PROFILE_KEEP_TABLE:-}" ]; then
 export LADI_TUNE_NO_SHIPPED=1
 export LADI_TUNE_CACHE=$O/r06_tune.txt
 rm -f $LADI_TUNE_CACHE
@@ -18,6 +20,7 @@ timeout 400 python bench.py --config 2 --no-cpu-baseline --no-roofline --no-tail
 timeout 400 python bench.py --config 4 --no-cpu-baseline --no-roofline --no-tail --steps 1 --warmup 0 > /dev/null 2>&1
 unset LADI_TUNE_NO_SHIPPED; unset LADI_TUNE_CACHE
 cp $O/r06_tune.txt ladi_vton_amd/tune_gfx950.txt
+fi
 wc -l ladi_vton_amd/tune_gfx950.txt
 # ---- 2. kernel traces and PMC passes of the roofline command (each counter set in its own run)
 cd /tmp; export TMPDIR=/tmp
