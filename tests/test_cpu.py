@@ -888,6 +888,118 @@ def test_committed_parity_record_is_one_run_and_holds_every_cited_key():
     assert len([k for k in blob if not k.startswith("_")]) >= 12, "a full GPU run records every measured tolerance, not a fragment"
 
 
+
+def test_halo_weight_slice_major_map_covers_every_tile_once():
+    """Host-side replay of igemm_halo_kernel.h's tile_map 3 decode (round 6): block b -> XCD b % 8, unit = (channel tile, K slice, group of G pixel
+    tiles), the G workgroups of a unit consecutive on ONE XCD.  Every (qt, pt, z) must be produced exactly once, the surplus blocks must return,
+    and all workgroups of a unit must share b % 8 -- for the launch populations the library uses it on and a few awkward ones."""
+    def decode(b, nq, np_, S, G):
+        npg = (np_ + G - 1) // G
+        xcd, loc = b & 7, b >> 3
+        ui, pi = loc // G, loc % G
+        u = ui * 8 + xcd
+        if u >= nq * S * npg:
+            return None
+        pg, qz = u % npg, u // npg
+        pt, qt, z = pg * G + pi, qz // S, qz % S
+        return None if pt >= np_ else (qt, pt, z, u, xcd)
+
+    for nq, np_, S in ((10, 24, 2), (10, 6, 4), (10, 16, 2), (5, 24, 1), (3, 13, 3), (7, 32, 2), (1, 2, 1)):
+        G = np_ if np_ <= 12 else (np_ + 1) // 2                     # the launcher's choice
+        units = nq * S * ((np_ + G - 1) // G)
+        blocks = 8 * ((units + 7) // 8) * G
+        seen, unit_xcd = {}, {}
+        for b in range(blocks):
+            d = decode(b, nq, np_, S, G)
+            if d is None:
+                continue
+            qt, pt, z, u, xcd = d
+            assert (qt, pt, z) not in seen, (nq, np_, S, qt, pt, z)
+            seen[(qt, pt, z)] = b
+            assert unit_xcd.setdefault(u, xcd) == xcd                # one XCD per unit
+        assert len(seen) == nq * np_ * S, (nq, np_, S, len(seen))
+        for u in unit_xcd:                                           # the workgroups of a unit are G CONSECUTIVE blocks of their XCD's sequence
+            bs = sorted(b for (qt, pt, z), b in seen.items() if (qt * S + z) * ((np_ + G - 1) // G) + pt // G == u)
+            locs = [b >> 3 for b in bs]
+            assert locs == list(range(locs[0], locs[0] + len(locs))), (nq, np_, S, u)
+
+
+def test_halo_folded_upsample_tables_emulation():
+    """Host-side replay of the folded-upsample halo form's addressing (igemm_halo_kernel.h UPS, round 6): the staged tile is the run of LOW-resolution
+    rows from source row (y0 - 1) >> 1 of the tile's first output row on; tap (dy, dx) of output pixel (y, x) reads staged row
+    (((y + dy - 1) >> 1) - r0) * Ws + ((x + dx - 1) >> 1), masked where the tap leaves the 2H x 2W image.  Replayed in numpy against
+    conv2d(interpolate(x, 2, nearest)) for tiles that start in the middle of an image row, first / last tiles of a sample and several tile sizes."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    F_ = torch.nn.functional
+    for (Hs, Ws, BP, rows_cap) in ((12, 24, 192, 290), (8, 12, 192, 242), (16, 12, 128, 226), (4, 8, 128, 226), (6, 4, 32, 64)):
+        Ho, Wo = 2 * Hs, 2 * Ws
+        assert (Ho * Wo) % BP == 0
+        x = rng.standard_normal((Hs * Ws,)).astype(np.float64)      # one channel is enough: the addressing is channel-independent
+        w = rng.standard_normal((3, 3)).astype(np.float64)
+        ref = F_.conv2d(F_.interpolate(torch.from_numpy(x).view(1, 1, Hs, Ws), scale_factor=2.0, mode="nearest"), torch.from_numpy(w).view(1, 1, 3, 3), padding=1).view(-1).numpy()
+        got = np.zeros(Ho * Wo)
+        for q0 in range(0, Ho * Wo, BP):
+            y0, y1 = q0 // Wo, (q0 + BP - 1) // Wo
+            r0 = (y0 - 1) >> 1
+            l0 = r0 * Ws
+            u_rows = (((y1 + 1) >> 1) - r0 + 1) * Ws
+            assert u_rows <= rows_cap                                # fits the halo buffer of the form that takes this shape
+            tile = np.zeros(u_rows)
+            for r in range(u_rows):                                  # DMA side: source pixel l0 + r, zero-filled outside the sample
+                lin = l0 + r
+                tile[r] = x[lin] if 0 <= lin < Hs * Ws else 0.0
+            for pl in range(BP):
+                q = q0 + pl
+                oy, ox = q // Wo, q % Wo
+                acc = 0.0
+                for dy in range(3):
+                    for dx in range(3):
+                        if not (0 <= oy + dy - 1 < Ho and 0 <= ox + dx - 1 < Wo):
+                            continue                                 # the validity bit: the lane reads the zero row
+                        row = (((oy + dy - 1) >> 1) - r0) * Ws + ((ox + dx - 1) >> 1)
+                        assert 0 <= row < u_rows
+                        acc += tile[row] * w[dy, dx]
+                got[q] = acc
+        assert np.allclose(got, ref, atol=1e-12), (Hs, Ws, BP)
+
+
+def test_gn_reduce_rows_fold_emulation():
+    """Host-side replay of norm.hip gn_reduce_rows_kernel (round 6): block (b, n) folds partial rows [b rps / 16, (b + 1) rps / 16) -- row lanes of
+    one float4 (two channels) each, four rows in flight, the lanes combined in lane order -- into 16 rows per sample whose sum is the sum of all rows;
+    including the C = 320 case (160 float4 pieces per row: ONE row lane, the threads beyond piece 159 must write nothing -- the race fixed this round)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for C, rps in ((128, 6144), (320, 123), (512, 768), (256, 97), (1280, 200)):
+        part = rng.standard_normal((rps, C, 2))
+        q = C // 2
+        lanes = 256 // q if q < 256 else 1
+        out = np.full((16, C, 2), np.nan)
+        for b in range(16):
+            r_lo, r_hi = b * rps // 16, (b + 1) * rps // 16
+            for q0 in range(0, q, 256):
+                acc = np.zeros((256, 4))
+                live = np.zeros(256, bool)
+                for tid in range(256):
+                    qi = q0 + (tid % q if q < 256 else tid)
+                    rl = tid // q if q < 256 else 0
+                    if rl < lanes and qi < q:
+                        live[tid] = True
+                        for r in range(r_lo + rl, r_hi, lanes):
+                            acc[tid] += part[r].reshape(-1)[4 * qi:4 * qi + 4]
+                if lanes > 1:
+                    for tid in range(q):
+                        t = sum(acc[l * q + tid] for l in range(lanes))
+                        out[b].reshape(-1)[4 * tid:4 * tid + 4] = t
+                else:
+                    for tid in range(256):
+                        qi = q0 + (tid % q if q < 256 else tid)
+                        if live[tid]:                                 # (the fixed kernel: `rl < lanes && qi < q`)
+                            out[b].reshape(-1)[4 * qi:4 * qi + 4] = acc[tid]
+        assert not np.isnan(out).any()
+        assert np.allclose(out.sum(0), part.sum(0), rtol=1e-10, atol=1e-9), (C, rps)
+
+
 def test_one_pass_group_norm_chunk_math_emulation():
     """Host-side replay of norm.hip gn_norm_kernel's index arithmetic (round 5): a block owns a 64-channel chunk, sums the partial rows of every
     group that overlaps the chunk (groups straddle chunk boundaries and the boundary of the two concat sources; the last chunk may be ragged),
