@@ -254,7 +254,8 @@ def hbm_kernels():
             k78 = name[:78]
             if k78 in fk and k78 in wk and us > 0:
                 b = 2.0 * fk[k78][0] * 1024.0 + wk[k78][0] * 1024.0
-                short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name).split("E", 1)[0] if name.startswith("_ZN") else name.replace("void ", "")
+                # mangled names of the anonymous-namespace kernels: keep the identifier (lower-case snake case), drop template arguments and signature
+                short = re.match(r"[a-z_0-9]+", re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)).group(0) if name.startswith("_ZN") else name.replace("void ", "")
                 rows[short[:60]] = {"GBps": round(b / us / 1e3, 1), "frac_of_8TBps": round(b / us / 1e3 / 8000.0, 3), "avg_us": us,
                                     "MB_per_launch": round(b / 1e6, 2), "launches": calls}
         res[leg] = dict(sorted(rows.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"])[:10])
