@@ -290,6 +290,29 @@ def traffic_committed(symbol):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the fp32 oracle (a port) on BASELINE configs[0], end to end
 # ---------------------------------------------------------------------------------------------------------------------------------
+def vendor_gemm_calibration(dev, achieved_tflops, nmk=8192, iters=30):
+    """one large fp16 GEMM through hipBLASLt (torch.matmul), timed with torch events on torch's current stream: the sustained dense-fp16 rate of
+    this box (profiles/r06_library_path.json: 1 379 TFLOP/s = 0.55 of the nominal peak).  Reported, never required."""
+    try:
+        g = torch.Generator(device=dev).manual_seed(7)
+        a_ = (torch.randn((nmk, nmk), device=dev, generator=g) * 0.05).half()
+        b_ = (torch.randn((nmk, nmk), device=dev, generator=g) * 0.05).half()
+        for _ in range(10):
+            torch.matmul(a_, b_)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            torch.matmul(a_, b_)
+        e1.record()
+        torch.cuda.synchronize()
+        tf = 2.0 * nmk ** 3 * iters / e0.elapsed_time(e1) / 1e9
+        return {"tflops": round(tf, 1), "shape": "%dx%dx%d fp16, torch.matmul (hipBLASLt)" % (nmk, nmk, nmk),
+                "dominant_kernel_over_vendor_gemm": round(achieved_tflops / tf, 4), "what": "comparison point only; the product path uses no vendor library"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:   # respect the container's cgroup CPU quota (the GPU box shows 256 logical CPUs but grants 16)
@@ -618,6 +641,9 @@ def main():
                         "clock": clock, "hbm_kernels": hbm_kernels() if default_workload else None,
                         "splitk_reduce": "charged to the symbol of the kernel that needed it (HIP events close after the reduce pass)",
                         "whole_path_frac": round(images_per_s / world * flop_img / 1e12 / PEAK_F16_TFLOPS, 4) if flop_img and a.steps else None}
+            # calibration of `peak` on THIS box: what the vendor's own GEMM sustains on its best shape (a comparison point measured live -- torch.matmul is
+            # hipBLASLt; nothing on the product path uses it).  `peak` stays the nominal 2.5 PFLOP/s at 2.4 GHz; the shader clock under this load is in `clock`.
+            roofline["vendor_gemm"] = vendor_gemm_calibration(dev, ach)
     cpu = None
     if want_cpu:
         try:
