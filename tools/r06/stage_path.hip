@@ -32,17 +32,18 @@ __device__ __forceinline__ void dma_stage(const char* Wm, const char* Xm, char* 
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(dst + j * 1024), 16, goff[j] + koff, 0, 0, 0);
     }
 }
-template <int MODE, int BQ, int BP, int D, int WPC>
+template <int MODE, int BQ, int BP, int D, int WPC, int WQN = 2>
 __global__ __launch_bounds__(256, WPC) void kloop(const char* __restrict__ Wm, const char* __restrict__ Xm, int K, int nbq, int xmap, int passes, float* out,
                                                    unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = BQ + BP;                      // rows of 128 bytes per stage
     constexpr int STAGE = ROWS * 128;
     constexpr int NI = ROWS / 32;                      // 1-KiB wave-instructions per wave per stage (8 rows each, 4 waves)
-    constexpr int TQ = BQ / 64, TP = BP / 64;          // 32x32 MFMA tiles per wave in each direction
+    constexpr int WPN_ = 4 / WQN;                      // waves along the pixel direction (WQN along the channel direction: 2 x 2, or 4 x 1)
+    constexpr int TQ = BQ / (32 * WQN), TP = BP / (32 * WPN_);   // 32x32 MFMA tiles per wave in each direction
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wq = wave & 1, wp = wave >> 1;
+    const int wq = wave % WQN, wp = wave / WQN;
     // xmap: the library's tile_map 1 -- block b runs on XCD b % 8; the pixel tiles are split over the XCDs (each XCD's L2 holds all of W and 1/8 of X), q fastest inside an XCD
     int bq = blockIdx.x % nbq, bp = blockIdx.x / nbq;
     if (xmap) { const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3, nbp8 = (int)(gridDim.x / nbq) >> 3; bq = i % nbq; bp = xcd * nbp8 + i / nbq; }
@@ -62,9 +63,9 @@ __global__ __launch_bounds__(256, WPC) void kloop(const char* __restrict__ Wm, c
     // fragment addresses: A (weights) rows wq*BQ/2 + i*32 + (lane & 31); B (pixels) rows BQ + wp*BP/2 + i*32 + (lane & 31); chunk (kk*2 + (lane >> 5)) ^ (row & 7)
     unsigned fa[TQ], fb[TP];
 #pragma unroll
-    for (int i = 0; i < TQ; ++i) fa[i] = (unsigned)(wq * (BQ / 2) + i * 32 + (lane & 31));
+    for (int i = 0; i < TQ; ++i) fa[i] = (unsigned)(wq * (BQ / WQN) + i * 32 + (lane & 31));
 #pragma unroll
-    for (int i = 0; i < TP; ++i) fb[i] = (unsigned)(BQ + wp * (BP / 2) + i * 32 + (lane & 31));
+    for (int i = 0; i < TP; ++i) fb[i] = (unsigned)(BQ + wp * (BP / WPN_) + i * 32 + (lane & 31));
     f32x16 acc[TQ][TP];
 #pragma unroll
     for (int i = 0; i < TQ; ++i)
@@ -135,7 +136,11 @@ __global__ __launch_bounds__(256, WPC) void kloop(const char* __restrict__ Wm, c
 #pragma unroll
                 for (int i = 0; i < TQ; ++i)
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) dst[i][kk] = *reinterpret_cast<const h16x8*>(wf + ((size_t)i * (K / 16) + (size_t)(s_ * 4 + kk)) * 1024);
+                    for (int kk = 0; kk < 4; ++kk) {
+                        // xmap >= 2: the (chunk, tap) walk of a 3x3 convolution over tap-major storage -- step s reads k16 blocks ((s % 9) * K / 9 + (s / 9) * 64) / 16 ..+3
+                        const int kb0 = xmap >= 2 ? (((s_ % 9) * (K / 9) + (s_ / 9) * 64) >> 4) : s_ * 4;
+                        dst[i][kk] = *reinterpret_cast<const h16x8*>(wf + ((size_t)i * (K / 16) + (size_t)(kb0 + kk)) * 1024);
+                    }
             };
             auto compute_a = [&](int buf, h16x8 (&av)[TQ][4]) {
                 const char* base = smem + buf * STAGE;
@@ -202,16 +207,16 @@ __global__ __launch_bounds__(256, WPC) void kloop(const char* __restrict__ Wm, c
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int MODE, int BQ, int BP, int D, int WPC>
+template <int MODE, int BQ, int BP, int D, int WPC, int WQN = 2>
 static void run(const char* W, const char* X, int Q, int P, int K, float* out, unsigned long long* cyc, const char* what, int xmap = 1) {
     const int nbq = Q / BQ, nbp = P / BP, blocks = nbq * nbp, passes = 20;
     const int smem = D * (BQ + BP) * 128;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kloop<MODE, BQ, BP, D, WPC>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kloop<MODE, BQ, BP, D, WPC, WQN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((kloop<MODE, BQ, BP, D, WPC>), dim3(blocks), dim3(256), smem, 0, W, X, K, nbq, xmap, 2, out, cyc);
+    hipLaunchKernelGGL((kloop<MODE, BQ, BP, D, WPC, WQN>), dim3(blocks), dim3(256), smem, 0, W, X, K, nbq, xmap, 2, out, cyc);
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((kloop<MODE, BQ, BP, D, WPC>), dim3(blocks), dim3(256), smem, 0, W, X, K, nbq, xmap, passes, out, cyc);
+    hipLaunchKernelGGL((kloop<MODE, BQ, BP, D, WPC, WQN>), dim3(blocks), dim3(256), smem, 0, W, X, K, nbq, xmap, passes, out, cyc);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     if (hipGetLastError() != hipSuccess) { printf("launch failed: %s\n", what); return; }
@@ -223,19 +228,19 @@ static void run(const char* W, const char* X, int Q, int P, int K, float* out, u
     const double steps = (double)passes * (K / 64);
     const double us_pass = ms * 1e3 / passes;
     const double flop = 2.0 * Q * P * K;
-    printf("%-34s map %d %3dx%-3d D=%d wg/CU<=%d blocks %4d  %7.1f us per K loop  %6.0f TFLOP/s-equivalent  %6.0f cycles per step (median wg, s_memtime)  LDS %3d KB\n", what, xmap, BQ, BP, D,
+    printf("%-34s map %d waves %dx%d %3dx%-3d D=%d wg/CU<=%d blocks %4d  %7.1f us per K loop  %6.0f TFLOP/s-equivalent  %6.0f cycles per step (median wg, s_memtime)  LDS %3d KB\n", what, xmap, WQN, 4 / WQN, BQ, BP, D,
            WPC, blocks, us_pass, (MODE == 0 || MODE == 2 || MODE >= 4) ? flop / us_pass / 1e6 : 0.0, (double)h[blocks / 2] / steps, smem / 1024);
 }
 
 int main() {
-    const int K = 1280, Qmax = 3840, Pmax = 12288;
+    const int K = 1280, Qmax = 3840, Pmax = 12288, KBIG = 5760;
     char *W = nullptr, *X = nullptr;
     float* out = nullptr;
     unsigned long long* cyc = nullptr;
-    (void)hipMalloc(reinterpret_cast<void**>(&W), (size_t)Qmax * K * 2 + 4096);
-    (void)hipMalloc(reinterpret_cast<void**>(&X), (size_t)Pmax * K * 2 + 4096);
-    (void)hipMemset(W, 0, (size_t)Qmax * K * 2 + 4096);
-    (void)hipMemset(X, 0, (size_t)Pmax * K * 2 + 4096);
+    (void)hipMalloc(reinterpret_cast<void**>(&W), (size_t)Qmax * KBIG * 2 + 4096);
+    (void)hipMalloc(reinterpret_cast<void**>(&X), (size_t)Pmax * KBIG * 2 + 4096);
+    (void)hipMemset(W, 0, (size_t)Qmax * KBIG * 2 + 4096);
+    (void)hipMemset(X, 0, (size_t)Pmax * KBIG * 2 + 4096);
     (void)hipMalloc(reinterpret_cast<void**>(&out), 4096 * 256 * 4);
     (void)hipMalloc(reinterpret_cast<void**>(&cyc), 4096 * 8);
     printf("== 3072 x 1280 x 1280 (the 16x12 projection: 240 tiles of 128x128, one workgroup per CU)\n");
@@ -280,5 +285,21 @@ int main() {
     run<0, 128, 128, 2, 2>(W, X, 640, 12288, K, out, cyc, "fragments + MFMA only");
     run<2, 128, 128, 2, 2>(W, X, 640, 12288, K, out, cyc, "LDS-DMA ring + MFMA");
     run<6, 128, 128, 2, 2>(W, X, 640, 12288, K, out, cyc, "W direct-to-VGPR, X resident");
+    printf("-- the same grid with the four waves as 4 x 1 (wave tile 32 channels x 128 pixels: every weight fragment is fetched by ONE wave, every pixel fragment read by all four)\n");
+    run<0, 128, 128, 2, 2, 4>(W, X, 640, 12288, K, out, cyc, "fragments + MFMA only");
+    run<2, 128, 128, 2, 2, 4>(W, X, 640, 12288, K, out, cyc, "LDS-DMA ring + MFMA");
+    run<6, 128, 128, 2, 2, 4>(W, X, 640, 12288, K, out, cyc, "W direct-to-VGPR, X resident");
+    run<5, 128, 128, 2, 2, 4>(W, X, 640, 12288, K, out, cyc, "W direct-to-VGPR, X ring + MFMA");
+    printf("-- 256 x 128 tiles, 4 x 1 waves of 64 x 128 (128 accumulators; 240 tiles, one workgroup per CU)\n");
+    run<0, 256, 128, 2, 1, 4>(W, X, 640 * 2, 6144, K, out, cyc, "fragments + MFMA only");
+    run<2, 256, 128, 2, 1, 4>(W, X, 640 * 2, 6144, K, out, cyc, "LDS-DMA ring + MFMA");
+    run<6, 256, 128, 2, 1, 4>(W, X, 640 * 2, 6144, K, out, cyc, "W direct-to-VGPR, X resident");
+    printf("-- K = 5760 (the real reduction length of conv 640 -> 640: 7.4 MB of weights against a 4 MB L2), 128 x 128 tiles, two workgroups per CU\n");
+    run<2, 128, 128, 2, 2>(W, X, 640, 12288, KBIG, out, cyc, "LDS-DMA ring + MFMA");
+    run<2, 128, 128, 2, 2, 4>(W, X, 640, 12288, KBIG, out, cyc, "LDS-DMA ring + MFMA");
+    run<6, 128, 128, 2, 2>(W, X, 640, 12288, KBIG, out, cyc, "W direct-to-VGPR, X resident");
+    run<6, 128, 128, 2, 2, 4>(W, X, 640, 12288, KBIG, out, cyc, "W direct-to-VGPR, X resident");
+    run<0, 128, 128, 2, 2, 4>(W, X, 640, 12288, KBIG, out, cyc, "fragments + MFMA only");
+    run<6, 128, 128, 2, 2, 4>(W, X, 640, 12288, KBIG, out, cyc, "W direct, X resident, TAP-MAJOR walk", 2);
     return 0;
 }
