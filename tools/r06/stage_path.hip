@@ -301,5 +301,12 @@ int main() {
     run<6, 128, 128, 2, 2, 4>(W, X, 640, 12288, KBIG, out, cyc, "W direct-to-VGPR, X resident");
     run<0, 128, 128, 2, 2, 4>(W, X, 640, 12288, KBIG, out, cyc, "fragments + MFMA only");
     run<6, 128, 128, 2, 2, 4>(W, X, 640, 12288, KBIG, out, cyc, "W direct, X resident, TAP-MAJOR walk", 2);
+    printf("-- does a third workgroup per CU (three waves per SIMD) hide a step's non-MFMA instructions?  768 tiles (Q = 1024), K = 5760, one LDS stage; the TAP-MAJOR walk carries a dozen extra address instructions per request\n");
+    run<6, 128, 128, 1, 2, 4>(W, X, 1024, 12288, KBIG, out, cyc, "W direct, X resident (2 per CU)");
+    run<6, 128, 128, 1, 2, 4>(W, X, 1024, 12288, KBIG, out, cyc, "  same, TAP-MAJOR walk (2 per CU)", 2);
+    run<6, 128, 128, 1, 3, 4>(W, X, 1024, 12288, KBIG, out, cyc, "W direct, X resident (3 per CU)");
+    run<6, 128, 128, 1, 3, 4>(W, X, 1024, 12288, KBIG, out, cyc, "  same, TAP-MAJOR walk (3 per CU)", 2);
+    run<6, 128, 128, 1, 4, 4>(W, X, 1024, 12288, KBIG, out, cyc, "W direct, X resident (4 per CU)");
+    run<6, 128, 128, 1, 4, 4>(W, X, 1024, 12288, KBIG, out, cyc, "  same, TAP-MAJOR walk (4 per CU)", 2);
     return 0;
 }
